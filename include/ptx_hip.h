@@ -1,0 +1,226 @@
+/*
+ * ptx_hip.h — C ABI of the MI355X (gfx950) path-tracing library, libptx_hip.so.
+ *
+ * This is the drop-in boundary for the hot path of filiprak/path-tracer:
+ * primary-ray generation with jitter, KD-tree traversal + ray/triangle/sphere
+ * intersection, the diffuse/specular/refractive bounce loop and the per-pixel
+ * float accumulation. Plain C types only: no HIP, torch or C++ types cross it.
+ * The C++ host layer (path-tracer_amd/host, reference entry-point names) and
+ * the Python harness (ctypes) both bind exactly these symbols.
+ *
+ * Every function returns PTX_OK (0) or a negative PTX_E_* code and stores a
+ * message retrievable with ptx_last_error() (thread-local). Nothing here falls
+ * back to a CPU path: without a gfx950 device every compute entry point fails
+ * with PTX_E_NO_DEVICE / PTX_E_HIP.
+ *
+ * Each declaration cites the reference interface (file:line under the
+ * reference tree) it replaces.
+ */
+#ifndef PTX_HIP_H
+#define PTX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTX_OK            0
+#define PTX_E_INVALID    -1   /* bad argument / shape mismatch (checked on the host before any launch) */
+#define PTX_E_NO_DEVICE  -2   /* no HIP device, or device index out of range */
+#define PTX_E_HIP        -3   /* a HIP runtime call failed; ptx_last_error() has hipGetErrorString */
+#define PTX_E_STATE      -4   /* call order violated (e.g. render before init) */
+#define PTX_E_LIMIT      -5   /* a documented limit was exceeded (KD depth, object count, texture count) */
+
+#define PTX_MAX_OBJECTS   32  /* reference: src/world_load.h:10 MAX_OBJECTS_NUM */
+#define PTX_MAX_KD_DEPTH  60  /* reference: src/intersect.cuh:139 `int stack[64]` */
+
+/* reference: src/world.h:10-14 WorldObjType, :17-23 MaterialType (same values) */
+enum { PTX_OBJ_SPHERE = 0, PTX_OBJ_MESH = 1 };
+enum { PTX_MAT_LUMINESCENT = 0, PTX_MAT_DIFFUSE = 1, PTX_MAT_SPECULAR = 2, PTX_MAT_TRANSPARENT = 3 };
+
+typedef struct PtxCtx PtxCtx;     /* one per GPU: device, stream, render buffers */
+typedef struct PtxScene PtxScene; /* device-resident scene in the packed SoA layout */
+
+/* reference: src/camera.h:8-43 (the fields the kernels read) */
+typedef struct PtxCamera {
+	float position[3];
+	float direction[3];
+	float up[3];
+	float right[3];
+	int32_t width, height;
+	float pixel_size;        /* projection.pixel_size.x */
+	float screen_half[2];    /* projection.screen_halfsize */
+	float screen_dist;
+	float aa_jitter;
+	float gamma_corr;
+	int32_t max_ray_bounces;
+	int32_t preview_mode;
+	int32_t aabb_mode;
+	int32_t texture_enabled;
+} PtxCamera;
+
+/* reference: src/world.h:28-43 Material */
+typedef struct PtxMaterial {
+	int32_t type;
+	float color[3];
+	int32_t texture;         /* -1 = none, else index into PtxSceneDesc::textures */
+	float emittance[3];
+	float reflect_factor;
+	float refract_index;
+	float sharpness;
+	int32_t _pad;
+} PtxMaterial;
+
+/* reference: src/world_load.cpp:131-192 loadTexture — float RGBA texels, rows already flipped */
+typedef struct PtxTexture {
+	const float* rgba;       /* width*height*4 floats, row-major */
+	int32_t width, height;
+} PtxTexture;
+
+/* reference: src/world.h:46-51 Triangle (b and c are not needed on the device) */
+typedef struct PtxTriangle {
+	float a[3], e1[3], e2[3];
+	float na[3], nb[3], nc[3];
+	float ta[2], tb[2], tc[2];
+	int32_t material;        /* index into the owning object's materials */
+} PtxTriangle;
+
+/* reference: src/world.h:61-78 KDNode as laid out by flatenKDTree (src/KDTree.cpp:152-163) */
+typedef struct PtxKDNode {
+	float bmin[3], bmax[3];
+	int32_t left, right;     /* indices inside the owning object's node range, -1 = none */
+	int32_t first_tri;       /* offset into the owning object's leaf_tris range (leaves only) */
+	int32_t num_tris;
+} PtxKDNode;
+
+/* reference: src/world.h:100-107 WorldObject + :81-96 geometry data */
+typedef struct PtxObject {
+	int32_t type;
+	int32_t first_material, num_materials;   /* range in PtxSceneDesc::materials */
+	float radius;                            /* sphere */
+	float position[3];                       /* sphere */
+	int32_t first_triangle, num_triangles;   /* mesh: range in ::triangles (original primitive order) */
+	int32_t first_node, num_nodes;           /* mesh: range in ::nodes, node 0 of the range is the root */
+	int32_t first_leaf_tri, num_leaf_tris;   /* mesh: range in ::leaf_tris */
+	int32_t max_depth;                       /* mesh: deepest node level (root = 0) */
+} PtxObject;
+
+typedef struct PtxSceneDesc {
+	int32_t num_objects;   const PtxObject* objects;
+	int32_t num_materials; const PtxMaterial* materials;
+	int32_t num_textures;  const PtxTexture* textures;
+	int32_t num_triangles; const PtxTriangle* triangles;
+	int32_t num_nodes;     const PtxKDNode* nodes;
+	int32_t num_leaf_tris; const int32_t* leaf_tris;   /* triangle indices inside the owning object's range */
+} PtxSceneDesc;
+
+/* Result of one rayIntersectsScene-equivalent query (parity entry point). */
+typedef struct PtxHit {
+	int32_t hit;            /* 0/1 */
+	int32_t object;         /* index of the closest object, -1 if none */
+	int32_t prim;           /* ORIGINAL triangle index inside that object, -1 for spheres/miss */
+	uint32_t t_bits;        /* bit pattern of length(ipoint - origin) of the closest hit */
+	uint32_t leaf_hash;     /* FNV-1a over (object, leaf node idx) in visit order, all meshes */
+	uint32_t n_inner;       /* inner-node steps */
+	uint32_t n_box;         /* box tests incl. root tests */
+	uint32_t n_tri;         /* triangle tests */
+	uint32_t n_leaf;        /* leaves visited */
+	float point[3];         /* ipoint */
+	float normal[3];        /* shading normal */
+	float bary[3];
+} PtxHit;
+
+/* Whole-render counters (device-side, reduced per wave). */
+typedef struct PtxStats {
+	uint64_t rays;          /* rayIntersectsScene-equivalent path segments */
+	uint64_t paths;         /* (pixel, sample) paths started */
+	uint64_t n_inner, n_box, n_tri, n_sphere, n_leaf;   /* filled by the *_stats render variant only */
+	uint64_t hit_mesh, hit_sphere, hit_textured;        /* idem */
+	uint64_t lane_steps_active, lane_steps_total;       /* idem: active lanes / (64 x wave iterations) of the segment loop */
+} PtxStats;
+
+/* BSDF known-answer entry (parity for surfaces.cuh). */
+typedef struct PtxBsdfCase {
+	float dir[3];           /* incoming ray direction */
+	float normal[3];
+	float point[3];
+	int32_t mat_type;
+	float reflect_factor, refract_index, sharpness;
+	float u[4];             /* the uniforms, consumed in call order */
+	/* outputs */
+	float out_origin[3];
+	float out_dir[3];
+	float out_mask[3];      /* multiplier applied to the path mask by the BSDF itself (1 unless Transparent) */
+} PtxBsdfCase;
+
+/* ---- library / device ------------------------------------------------------------------- */
+const char* ptx_last_error(void);
+const char* ptx_version(void);
+/* reference: src/main.cpp:22-41 detectCUDAdevice / src/cudaUtility.cpp:6-28 printCudaDevicesInfo */
+int ptx_device_count(void);
+int ptx_device_info(int device, char* name, int name_len, int* compute_units, int* clock_khz, uint64_t* total_mem);
+int ptx_ctx_create(int device, PtxCtx** out);
+int ptx_ctx_destroy(PtxCtx* ctx);
+
+/* ---- scene --------------------------------------------------------------------------------
+ * reference: src/world_load.cpp:509-530 loadWorldObjects + the per-object cudaMalloc/cudaMemcpy in
+ * loadSphereObj (:385-410), loadTriangleMeshObj (:412-507), loadTexture (:131-192) and
+ * flatenKDTree (src/KDTree.cpp:152-163). One packed upload replaces them all. */
+int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* desc, PtxScene** out);
+/* reference: src/world_load.cpp:553-574 freeWorldObjects */
+int ptx_scene_free(PtxCtx* ctx, PtxScene* scene);
+int64_t ptx_scene_device_bytes(const PtxScene* scene);
+
+/* ---- render -------------------------------------------------------------------------------
+ * reference: src/kernel.cu:22-28 kernelInit + src/pathtracing.cu:44-62 initPathTracing.
+ * Allocates and zeroes the float4 accumulation buffer (width*height*16 B) unless the caller
+ * hands in its own device buffer `external_accum` (e.g. a torch tensor used for the RCCL
+ * all-reduce); primary rays are regenerated in-kernel, so no ray buffers exist. */
+int ptx_render_init(PtxCtx* ctx, const PtxCamera* cam, void* external_accum);
+/* reference: src/pathtracing.cu:166-172 (camera.changed → regenerate rays); resolution must not change */
+int ptx_render_set_camera(PtxCtx* ctx, const PtxCamera* cam);
+/* reference: src/kernel.cu:30-35 kernelCleanUp */
+int ptx_render_cleanup(PtxCtx* ctx);
+/* reference: src/kernel.cu:69-72 (iter == 1 → clear) */
+int ptx_accum_clear(PtxCtx* ctx);
+/* reference: src/kernel.cu:59-81 kernelMain → src/pathtracing.cu:156-182 runPathTracing, called
+ * num_samples times: renders global samples [first_sample, first_sample + num_samples) of every
+ * pixel (sample i ↔ reference iteration i+1) and adds them, in sample order, into the accumulation
+ * buffer. Asynchronous on the context's stream. `collect_stats` != 0 runs the counting variant. */
+int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
+                       uint64_t seed, int collect_stats);
+int ptx_render_sync(PtxCtx* ctx);
+/* accumulation buffer access (headless replacement for the mapped PBO, src/kernel.h:6-8) */
+void* ptx_accum_device_ptr(PtxCtx* ctx);
+int ptx_accum_download(PtxCtx* ctx, float* rgba_host);
+int ptx_accum_upload(PtxCtx* ctx, const float* rgba_host);
+/* reference: src/kernel.cu:40-54 writeImageToPBO: uchar = 255*pow(clamp(acc/iter,0,1),gamma), w = 0;
+ * written to a HOST rgba8 buffer of width*height*4 bytes, in buffer order (not mirrored). */
+int ptx_tonemap(PtxCtx* ctx, int iter, float gamma, unsigned char* rgba8_host);
+int ptx_stats_get(PtxCtx* ctx, PtxStats* out);
+int ptx_stats_reset(PtxCtx* ctx);
+/* HIP-event timer on the context's stream (for bench.py's roofline leg). */
+int ptx_timer_begin(PtxCtx* ctx);
+int ptx_timer_end(PtxCtx* ctx, float* elapsed_ms);
+
+/* ---- parity entry points (same device functions as the render kernel) -------------------------
+ * reference: src/intersect.cuh:322-350 rayIntersectsScene on caller-supplied rays.
+ * origins/dirs: n*3 floats on the host. `object` = -1 intersects the whole scene, else only that
+ * object (rayIntersectsObject, src/intersect.cuh:260-319). */
+int ptx_trace_rays(PtxCtx* ctx, const PtxScene* scene, int n, const float* origins, const float* dirs,
+                   int object, PtxHit* hits_host);
+/* reference: src/pathtracing.cu:73-94 generatePrimaryRays (+ :107-129 jitterPrimaryRays when
+ * sample >= 0). Writes width*height*3 floats each, pixel index = x + y*width. */
+int ptx_generate_rays(PtxCtx* ctx, const PtxCamera* cam, int sample, uint64_t seed,
+                      float* origins_host, float* dirs_host);
+/* reference: src/surfaces.cuh:37-137 on explicit inputs */
+int ptx_bsdf_eval(PtxCtx* ctx, int n, PtxBsdfCase* cases_host);
+/* reference: src/radiance.cuh:15-87 gatherRadiance for ONE sample of every pixel, not accumulated:
+ * writes width*height*3 floats (rgb radiance of global sample `sample`). */
+int ptx_radiance_sample(PtxCtx* ctx, const PtxScene* scene, int sample, uint64_t seed, float* rgb_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTX_HIP_H */

@@ -1,0 +1,66 @@
+// Device-resident scene layout (what ptx_scene_upload packs; DESIGN.md "Data layout in HBM").
+//
+// The reference keeps 80-B KDNode / 128-B Triangle AoS records, child boxes inside the child
+// nodes and one device allocation per node for its triangle index list (reference:
+// src/world.h:46-78, src/KDTree.cpp:152-163). Here, per scene, five flat arrays:
+//
+//   nodes      4 x float4 per node (64 B, one record = half a 128-B L2 line):
+//                q0 = (L.min.x, L.min.y, L.min.z, L.max.x)
+//                q1 = (L.max.y, L.max.z, R.min.x, R.min.y)
+//                q2 = (R.min.z, R.max.x, R.max.y, R.max.z)
+//                q3 = int4(left, right, tri_first, tri_count)
+//              L/R = the CHILDREN's boxes, stored in the parent so one record serves both
+//              box tests of an inner step; left/right are scene-global node indices (-1 = none);
+//              tri_first/tri_count address tri_geom/tri_shade (leaves only).
+//   tri_geom   3 x float4 per triangle (48 B), stored in LEAF ORDER (the KD build partitions
+//              triangles, every triangle is in exactly one leaf, so leaf lists become
+//              contiguous runs and the reference's trg_idxs indirection disappears):
+//                g0 = (a.x, a.y, a.z, e1.x)  g1 = (e1.y, e1.z, e2.x, e2.y)
+//                g2 = (e2.z, int original_prim_id, int leaf_node_local_idx, 0)
+//   tri_shade  4 x float4 per triangle (64 B), same order, touched once per mesh hit:
+//                s0 = (na.xyz, ta.x) s1 = (nb.xyz, ta.y) s2 = (nc.xyz, tb.x)
+//                s3 = (tb.y, tc.x, tc.y, int material_global_idx)
+//   materials  3 x float4 per material (48 B):
+//                m0 = (int type, color.rgb) m1 = (int texture, emittance.rgb)
+//                m2 = (reflect_factor, refract_index, sharpness, 0)
+//   objects    DevObject[num_objects] (64 B each), read with wave-uniform indices (scalar loads)
+//   textures   DevTexture[num_textures] + one float4 texel array each
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct DevObject {
+	int32_t type;
+	int32_t mat_first;      // scene-global index of the object's material 0
+	int32_t root_node;      // scene-global node index of the root (-1 for empty meshes)
+	int32_t num_triangles;
+	float radius;
+	float px, py, pz;
+	float bmin[3];          // root box (mesh)
+	int32_t first_node;     // scene-global index of node 0 (to report local leaf ids)
+	float bmax[3];
+	int32_t pad;
+};
+
+struct DevTexture {
+	const float4* texels;
+	int32_t width, height;
+};
+
+struct DevScene {
+	const DevObject* objects;
+	const float4* nodes;
+	const float4* tri_geom;
+	const float4* tri_shade;
+	const float4* materials;
+	const DevTexture* textures;
+	int32_t num_objects;
+	int32_t stack_entries;  // LDS traversal-stack slots per lane (>= deepest tree level, >= 1)
+};
+
+struct DevCamera {
+	float pos[3], dir[3], up[3], right[3];
+	int32_t width, height;
+	float pixel_size, half_x, half_y, screen_dist, aa_jitter;
+	int32_t max_bounces, preview_mode, aabb_mode, texture_enabled;
+};

@@ -1,0 +1,261 @@
+// Ray / box / triangle / sphere tests and the short-stack KD traversal, one ray per lane.
+//
+// Semantics follow the reference function by function (cited at each one); what is new is
+// the data layout (pt_scene.h), the LDS-resident traversal stack (one column per lane,
+// stack[level][lane] so a wave's push/pop hits 64 different banks... 32 banks twice),
+// and the loop shape: a lane runs "descend until a leaf" and "test the leaf's triangles"
+// as two inner loops so that lanes of a wave spend their iterations in the same kind of
+// work. The order of operations seen by ONE ray is exactly the reference's, so hit ids,
+// visited leaves and tie-breaks are bit-identical whatever the scheduling.
+#pragma once
+#include "pt_math.h"
+#include "pt_scene.h"
+
+#define PT_TRI_EPSILON 0.00000005f   // reference: src/intersect.cuh:10
+
+enum { PT_F_STATS = 1, PT_F_DEBUGMASK = 2 };
+
+struct Ray {
+	f3 o, d, inv;
+	bool sx, sy, sz; // inv component < 0 (reference: src/pathtracing.cu:28-30)
+};
+
+// reference: src/pathtracing.cu:23-31 init_ray
+PT_DEV void init_ray(Ray& r, f3 orig, f3 dir) {
+	r.d = dir;
+	r.o = orig;
+	r.inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+	r.sx = r.inv.x < 0.0f;
+	r.sy = r.inv.y < 0.0f;
+	r.sz = r.inv.z < 0.0f;
+}
+
+struct TraceCounters {
+	uint32_t n_inner, n_box, n_tri, n_leaf, n_sphere, leaf_hash;
+};
+
+PT_DEV void fnv_word(uint32_t& h, uint32_t w) {
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		h ^= (w >> (8 * i)) & 0xFFu;
+		h *= 16777619u;
+	}
+}
+
+// reference: src/intersect.cuh:87-114 testBBoxIntersection. Written with the reference's
+// comparisons (not fmin/fmax) so NaNs from 0*inf take the same branches; a box wholly behind
+// the origin still "hits" with tmin = 0, as in the reference.
+PT_DEV bool box_test(float minx, float miny, float minz, float maxx, float maxy, float maxz,
+                     const Ray& r, float& tmin) {
+	float t1 = ((r.sx ? maxx : minx) - r.o.x) * r.inv.x;
+	float t2 = ((r.sx ? minx : maxx) - r.o.x) * r.inv.x;
+	float t3 = ((r.sy ? maxy : miny) - r.o.y) * r.inv.y;
+	float t4 = ((r.sy ? miny : maxy) - r.o.y) * r.inv.y;
+	if ((t1 > t4) || (t3 > t2)) return false;
+	if (t3 > t1) t1 = t3;
+	if (t4 < t2) t2 = t4;
+	float t5 = ((r.sz ? maxz : minz) - r.o.z) * r.inv.z;
+	float t6 = ((r.sz ? minz : maxz) - r.o.z) * r.inv.z;
+	if ((t1 > t6) || (t5 > t2)) return false;
+	if (t5 > t1) t1 = t5;
+	tmin = t1 < 0.0f ? 0.0f : t1;
+	return true;
+}
+
+// reference: src/intersect.cuh:27-56 rayIntersectsTriangle (Moeller-Trumbore on a, e1, e2;
+// __fdividef(1, a) is taken as the IEEE quotient 1.0f / a).
+PT_DEV bool tri_test(const Ray& r, f3 va, f3 e1, f3 e2, float& res_t, float& ru, float& rv) {
+	f3 h = cross3(r.d, e2);
+	float a = dot3(e1, h);
+	if (a > -PT_TRI_EPSILON && a < PT_TRI_EPSILON) return false;
+	float f = 1.0f / a;
+	f3 s = r.o - va;
+	float u = f * dot3(s, h);
+	if (u < 0.0f || u > 1.0f) return false;
+	f3 q = cross3(s, e1);
+	float v = f * dot3(r.d, q);
+	if (v < 0.0f || u + v > 1.0f) return false;
+	float t = f * dot3(e2, q);
+	if (t > PT_TRI_EPSILON) {
+		res_t = t; ru = u; rv = v;
+		return true;
+	}
+	return false;
+}
+
+// reference: src/intersect.cuh:59-83 testSphereIntersection
+PT_DEV bool sphere_test(const Ray& r, float rad, f3 center, f3& hit_point, f3& hit_norm) {
+	f3 op = center - r.o;
+	const float epsilon = 0.0001f;
+	float b = dot3(op, r.d);
+	float disc = b * b - dot3(op, op) + rad * rad;
+	if (disc < 0.0f) return false;
+	disc = __fsqrt_rn(disc);
+	float t = b - disc;
+	if (t < epsilon) t = b + disc;
+	if (t < epsilon) return false;
+	hit_point = r.o + r.d * t;
+	hit_norm = normalize3(hit_point - center);
+	return true;
+}
+
+// reference: src/intersect.cuh:119-212 rayIntersectsKDNodeLOOP.
+// stack: this lane's column in LDS, element i at stack[i * stride].
+// Returns "some triangle test succeeded"; best_tri (index into tri_geom/tri_shade), bu, bv and
+// tmin are updated only when a strictly closer hit is found (strict <, first wins ties).
+template <int FLAGS>
+PT_DEV bool traverse_mesh(const DevScene& sc, const DevObject& ob, int obj_index, const Ray& ray,
+                          int* stack, int stride, float& tmin, int& best_tri, float& bu, float& bv,
+                          TraceCounters& cnt, float& dbg) {
+	if (ob.root_node < 0) return false;
+	float dist;
+	if (FLAGS & PT_F_STATS) cnt.n_box++;
+	if (!box_test(ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], ray, dist))
+		return false;
+	if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
+
+	bool intersects = false;
+	int sp = 0;          // number of entries on the stack
+	int curr = ob.root_node;
+	const float4* __restrict__ nodes = sc.nodes;
+	const float4* __restrict__ geom = sc.tri_geom;
+
+	while (curr >= 0) {
+		const float4 q3 = nodes[4 * curr + 3];
+		const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+		if (left == -1 && right == -1) {
+			// leaf: test all triangles of the node, in list order
+			const int first = __float_as_int(q3.z), count = __float_as_int(q3.w);
+			if (FLAGS & PT_F_STATS) {
+				cnt.n_leaf++;
+				cnt.n_tri += (uint32_t)count;
+				fnv_word(cnt.leaf_hash, (uint32_t)obj_index);
+				fnv_word(cnt.leaf_hash, (uint32_t)(curr - ob.first_node));
+			}
+			for (int i = 0; i < count; ++i) {
+				const float4 g0 = geom[3 * (first + i) + 0];
+				const float4 g1 = geom[3 * (first + i) + 1];
+				const float4 g2 = geom[3 * (first + i) + 2];
+				float t, u, v;
+				if (tri_test(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
+					intersects = true;
+					if (t < tmin) {
+						tmin = t;
+						best_tri = first + i;
+						bu = u;
+						bv = v;
+					}
+				}
+			}
+			// pop
+			if (sp == 0) break;
+			--sp;
+			curr = stack[sp * stride];
+			continue;
+		}
+
+		// inner node: test both child boxes (stored in this record)
+		const float4 q0 = nodes[4 * curr + 0];
+		const float4 q1 = nodes[4 * curr + 1];
+		const float4 q2 = nodes[4 * curr + 2];
+		if (FLAGS & PT_F_STATS) cnt.n_inner++;
+		float left_dist = __builtin_huge_valf(), right_dist = __builtin_huge_valf();
+		bool left_res = false, right_res = false;
+		if (left != -1) {
+			if (FLAGS & PT_F_STATS) cnt.n_box++;
+			left_res = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ray, left_dist) && (left_dist < tmin);
+		}
+		if (right != -1) {
+			if (FLAGS & PT_F_STATS) cnt.n_box++;
+			right_res = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ray, right_dist) && (right_dist < tmin);
+		}
+		if (left_res && right_res) {
+			// nearer child first; tie -> left first (reference :183-187)
+			int further = right;
+			int next = right;
+			if (left_dist > right_dist) further = left; else next = left;
+			stack[sp * stride] = further;
+			++sp;
+			curr = next;
+			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.9025f;
+		} else if (left_res) {
+			curr = left;
+			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
+		} else if (right_res) {
+			curr = right;
+			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
+		} else {
+			if (sp == 0) break;
+			--sp;
+			curr = stack[sp * stride];
+		}
+	}
+	return intersects;
+}
+
+struct HitInfo {
+	f3 point, normal, bary;
+	int object;   // -1 = miss
+	int tri;      // device triangle index (meshes), -1 for spheres
+	int material; // scene-global material index
+	float dist;   // length(point - origin)
+};
+
+// reference: src/intersect.cuh:322-350 rayIntersectsScene + :260-319 rayIntersectsObject.
+// only_object >= 0 restricts the loop to that object (parity entry point).
+template <int FLAGS>
+PT_DEV bool intersect_scene(const DevScene& sc, const Ray& ray, int* stack, int stride, int only_object,
+                            HitInfo& hi, TraceCounters& cnt, float& dbg) {
+	bool intersects = false;
+	float closest = __builtin_huge_valf();
+	hi.object = -1;
+	hi.tri = -1;
+	hi.material = 0;
+	hi.dist = closest;
+	const int n = sc.num_objects;
+	for (int i = 0; i < n; ++i) {
+		if (only_object >= 0 && i != only_object) continue;
+		const DevObject& ob = sc.objects[i];
+		f3 p, nrm, bary = mk3(0.0f);
+		int tri = -1;
+		int mat = ob.mat_first;
+		bool hit;
+		if (ob.type == 0) {
+			if (FLAGS & PT_F_STATS) cnt.n_sphere++;
+			hit = sphere_test(ray, ob.radius, mk3(ob.px, ob.py, ob.pz), p, nrm);
+		} else {
+			float tmin = __builtin_huge_valf();
+			float bu = 0.0f, bv = 0.0f;
+			hit = traverse_mesh<FLAGS>(sc, ob, i, ray, stack, stride, tmin, tri, bu, bv, cnt, dbg);
+			if (hit) {
+				// reference :300-305
+				p = ray.o + tmin * ray.d;
+				bary.y = bu;
+				bary.z = bv;
+				bary.x = 1.0f - bary.y - bary.z;
+				const float4 s0 = sc.tri_shade[4 * tri + 0];
+				const float4 s1 = sc.tri_shade[4 * tri + 1];
+				const float4 s2 = sc.tri_shade[4 * tri + 2];
+				const float4 s3 = sc.tri_shade[4 * tri + 3];
+				nrm = normalize3(bary.x * mk3(s0.x, s0.y, s0.z) + bary.y * mk3(s1.x, s1.y, s1.z) +
+				                 bary.z * mk3(s2.x, s2.y, s2.z));
+				mat = __float_as_int(s3.w);
+			}
+		}
+		if (hit) {
+			intersects = true;
+			float d = length3(p - ray.o);
+			if (d < closest) {
+				closest = d;
+				hi.object = i;
+				hi.point = p;
+				hi.normal = nrm;
+				hi.bary = bary;
+				hi.material = mat;
+				hi.tri = tri;
+				hi.dist = d;
+			}
+		}
+	}
+	return intersects;
+}

@@ -1,0 +1,584 @@
+// libptx_hip.so — C ABI (include/ptx_hip.h) over the gfx950 kernels in pt_kernels.h.
+// Host side of the library: argument validation, the packed scene upload, launches.
+// There is no CPU fallback anywhere in this file: without a HIP device every compute
+// entry point returns an error.
+#include "pt_kernels.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+	char buf[1024];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	g_last_error = buf;
+	return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+	do {                                                                                            \
+		hipError_t e_ = (expr);                                                                     \
+		if (e_ != hipSuccess)                                                                       \
+			return fail(PTX_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+	} while (0)
+
+struct PtxCtx {
+	int device;
+	hipStream_t stream;
+	bool has_render;
+	DevCamera cam;
+	float4* accum;
+	bool owns_accum;
+	PtxStats* d_stats;
+	uchar4* d_pbo;        // tonemap output staging (device)
+	size_t pbo_pixels;
+	hipEvent_t ev0, ev1;
+	bool timer_open;
+};
+
+struct PtxScene {
+	int device;
+	DevScene dev;
+	std::vector<void*> allocs;
+	int64_t bytes;
+	int num_objects;
+	int max_depth;
+	int num_dev_triangles;
+};
+
+extern "C" const char* ptx_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* ptx_version(void) { return "ptx_hip 0.1 (gfx950)"; }
+
+extern "C" int ptx_device_count(void) {
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess) {
+		fail(PTX_E_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+		return 0;
+	}
+	return n;
+}
+
+extern "C" int ptx_device_info(int device, char* name, int name_len, int* compute_units, int* clock_khz,
+                               uint64_t* total_mem) {
+	int n = ptx_device_count();
+	if (device < 0 || device >= n) return fail(PTX_E_NO_DEVICE, "device %d out of range (%d devices)", device, n);
+	hipDeviceProp_t p;
+	HIP_TRY(hipGetDeviceProperties(&p, device));
+	if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+	if (compute_units) *compute_units = p.multiProcessorCount;
+	if (clock_khz) *clock_khz = p.clockRate;
+	if (total_mem) *total_mem = (uint64_t)p.totalGlobalMem;
+	return PTX_OK;
+}
+
+extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
+	if (!out) return fail(PTX_E_INVALID, "ptx_ctx_create: out is NULL");
+	*out = NULL;
+	int n = ptx_device_count();
+	if (n <= 0) return fail(PTX_E_NO_DEVICE, "no HIP device available (the product has no CPU path)");
+	if (device < 0 || device >= n) return fail(PTX_E_NO_DEVICE, "device %d out of range (%d devices)", device, n);
+	HIP_TRY(hipSetDevice(device));
+	PtxCtx* c = new PtxCtx();
+	memset(c, 0, sizeof(*c));
+	c->device = device;
+	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+	if (e != hipSuccess) { delete c; return fail(PTX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+	e = hipMalloc((void**)&c->d_stats, sizeof(PtxStats));
+	if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return fail(PTX_E_HIP, "hipMalloc stats: %s", hipGetErrorString(e)); }
+	hipMemsetAsync(c->d_stats, 0, sizeof(PtxStats), c->stream);
+	hipEventCreate(&c->ev0);
+	hipEventCreate(&c->ev1);
+	*out = c;
+	return PTX_OK;
+}
+
+extern "C" int ptx_render_cleanup(PtxCtx* ctx);
+
+extern "C" int ptx_ctx_destroy(PtxCtx* ctx) {
+	if (!ctx) return PTX_OK;
+	hipSetDevice(ctx->device);
+	hipStreamSynchronize(ctx->stream);
+	ptx_render_cleanup(ctx);
+	if (ctx->d_stats) hipFree(ctx->d_stats);
+	if (ctx->d_pbo) hipFree(ctx->d_pbo);
+	hipEventDestroy(ctx->ev0);
+	hipEventDestroy(ctx->ev1);
+	hipStreamDestroy(ctx->stream);
+	delete ctx;
+	return PTX_OK;
+}
+
+// ---- scene upload -----------------------------------------------------------------------------
+
+static inline float as_float(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
+
+template <typename T>
+static int upload_vec(PtxCtx* ctx, PtxScene* s, const std::vector<T>& v, const T** out) {
+	*out = NULL;
+	size_t bytes = v.size() * sizeof(T);
+	if (bytes == 0) bytes = sizeof(T); // keep pointers non-null and loads in-bounds for empty scenes
+	void* d = NULL;
+	HIP_TRY(hipMalloc(&d, bytes));
+	s->allocs.push_back(d);
+	s->bytes += (int64_t)bytes;
+	if (!v.empty()) HIP_TRY(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+	else HIP_TRY(hipMemsetAsync(d, 0, bytes, ctx->stream));
+	*out = (const T*)d;
+	return PTX_OK;
+}
+
+static void free_scene_allocs(PtxScene* s) {
+	for (size_t i = 0; i < s->allocs.size(); ++i) hipFree(s->allocs[i]);
+	s->allocs.clear();
+}
+
+extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** out) {
+	if (!ctx || !d || !out) return fail(PTX_E_INVALID, "ptx_scene_upload: NULL argument");
+	*out = NULL;
+	if (d->num_objects < 0 || d->num_objects > PTX_MAX_OBJECTS)
+		return fail(PTX_E_LIMIT, "num_objects %d outside [0, %d]", d->num_objects, PTX_MAX_OBJECTS);
+	if (d->num_materials < 0 || d->num_textures < 0 || d->num_triangles < 0 || d->num_nodes < 0 || d->num_leaf_tris < 0)
+		return fail(PTX_E_INVALID, "negative element count in scene description");
+	if ((d->num_objects && !d->objects) || (d->num_materials && !d->materials) || (d->num_textures && !d->textures) ||
+	    (d->num_triangles && !d->triangles) || (d->num_nodes && !d->nodes) || (d->num_leaf_tris && !d->leaf_tris))
+		return fail(PTX_E_INVALID, "NULL array with non-zero count in scene description");
+	for (int t = 0; t < d->num_textures; ++t)
+		if (!d->textures[t].rgba || d->textures[t].width <= 0 || d->textures[t].height <= 0)
+			return fail(PTX_E_INVALID, "texture %d is empty", t);
+	for (int m = 0; m < d->num_materials; ++m) {
+		const PtxMaterial& pm = d->materials[m];
+		if (pm.type < 0 || pm.type > 3) return fail(PTX_E_INVALID, "material %d: type %d", m, pm.type);
+		if (pm.texture < -1 || pm.texture >= d->num_textures) return fail(PTX_E_INVALID, "material %d: texture %d out of range", m, pm.texture);
+	}
+
+	std::vector<DevObject> objs((size_t)d->num_objects);
+	std::vector<float4> nodes, geom, shade, mats;
+	nodes.reserve((size_t)d->num_nodes * 4);
+	geom.reserve((size_t)d->num_leaf_tris * 3);
+	shade.reserve((size_t)d->num_leaf_tris * 4);
+	int scene_max_depth = 0;
+
+	for (int m = 0; m < d->num_materials; ++m) {
+		const PtxMaterial& pm = d->materials[m];
+		mats.push_back(make_float4(as_float(pm.type), pm.color[0], pm.color[1], pm.color[2]));
+		mats.push_back(make_float4(as_float(pm.texture), pm.emittance[0], pm.emittance[1], pm.emittance[2]));
+		mats.push_back(make_float4(pm.reflect_factor, pm.refract_index, pm.sharpness, 0.0f));
+	}
+
+	for (int oi = 0; oi < d->num_objects; ++oi) {
+		const PtxObject& o = d->objects[oi];
+		DevObject& dv = objs[(size_t)oi];
+		memset(&dv, 0, sizeof(dv));
+		if (o.type != PTX_OBJ_SPHERE && o.type != PTX_OBJ_MESH) return fail(PTX_E_INVALID, "object %d: type %d", oi, o.type);
+		if (o.num_materials < 1 || o.first_material < 0 || o.first_material + o.num_materials > d->num_materials)
+			return fail(PTX_E_INVALID, "object %d: material range [%d,+%d) outside %d materials", oi, o.first_material, o.num_materials, d->num_materials);
+		dv.type = o.type;
+		dv.mat_first = o.first_material;
+		dv.root_node = -1;
+		if (o.type == PTX_OBJ_SPHERE) {
+			dv.radius = o.radius;
+			dv.px = o.position[0]; dv.py = o.position[1]; dv.pz = o.position[2];
+			continue;
+		}
+		if (o.num_triangles < 0 || o.first_triangle < 0 || o.first_triangle + o.num_triangles > d->num_triangles)
+			return fail(PTX_E_INVALID, "object %d: triangle range outside scene", oi);
+		if (o.num_nodes < 0 || o.first_node < 0 || o.first_node + o.num_nodes > d->num_nodes)
+			return fail(PTX_E_INVALID, "object %d: node range outside scene", oi);
+		if (o.num_leaf_tris < 0 || o.first_leaf_tri < 0 || o.first_leaf_tri + o.num_leaf_tris > d->num_leaf_tris)
+			return fail(PTX_E_INVALID, "object %d: leaf triangle range outside scene", oi);
+		dv.num_triangles = o.num_triangles;
+		if (o.num_nodes == 0 || o.num_triangles == 0) continue; // empty mesh: never hit
+
+		const PtxKDNode* on = d->nodes + o.first_node;
+		const int base = (int)(nodes.size() / 4);
+		dv.first_node = base;
+		dv.root_node = base;
+		for (int k = 0; k < 3; ++k) { dv.bmin[k] = on[0].bmin[k]; dv.bmax[k] = on[0].bmax[k]; }
+
+		// Walk the tree from the root: checks that it IS a tree (every node reached once, so the
+		// device loop terminates) and measures its depth for the LDS stack.
+		std::vector<unsigned char> seen((size_t)o.num_nodes, 0);
+		std::vector<std::pair<int, int> > todo; // (node, depth)
+		todo.push_back(std::make_pair(0, 0));
+		int depth_max = 0;
+		nodes.resize(nodes.size() + (size_t)o.num_nodes * 4, make_float4(0, 0, 0, 0));
+		// nodes never reached stay as zero records with left=right=0 ... make them harmless leaves
+		for (int k = 0; k < o.num_nodes; ++k)
+			nodes[(size_t)(base + k) * 4 + 3] = make_float4(as_float(-1), as_float(-1), as_float(0), as_float(0));
+		while (!todo.empty()) {
+			const int ni = todo.back().first, dep = todo.back().second;
+			todo.pop_back();
+			if (ni < 0 || ni >= o.num_nodes) return fail(PTX_E_INVALID, "object %d: child index %d outside node range", oi, ni);
+			if (seen[(size_t)ni]) return fail(PTX_E_INVALID, "object %d: node %d reached twice (not a tree)", oi, ni);
+			seen[(size_t)ni] = 1;
+			if (dep > depth_max) depth_max = dep;
+			if (dep > PTX_MAX_KD_DEPTH) return fail(PTX_E_LIMIT, "object %d: KD depth exceeds %d", oi, PTX_MAX_KD_DEPTH);
+			const PtxKDNode& nd = on[ni];
+			float4* rec = &nodes[(size_t)(base + ni) * 4];
+			const bool leaf = nd.left == -1 && nd.right == -1;
+			if (leaf) {
+				if (nd.num_tris < 0 || nd.first_tri < 0 || nd.first_tri + nd.num_tris > o.num_leaf_tris)
+					return fail(PTX_E_INVALID, "object %d node %d: leaf triangle list outside range", oi, ni);
+				const int first_dev = (int)(geom.size() / 3);
+				for (int k = 0; k < nd.num_tris; ++k) {
+					const int ti = d->leaf_tris[o.first_leaf_tri + nd.first_tri + k];
+					if (ti < 0 || ti >= o.num_triangles) return fail(PTX_E_INVALID, "object %d node %d: triangle index %d", oi, ni, ti);
+					const PtxTriangle& t = d->triangles[o.first_triangle + ti];
+					if (t.material < 0 || t.material >= o.num_materials)
+						return fail(PTX_E_INVALID, "object %d triangle %d: material %d outside [0,%d)", oi, ti, t.material, o.num_materials);
+					geom.push_back(make_float4(t.a[0], t.a[1], t.a[2], t.e1[0]));
+					geom.push_back(make_float4(t.e1[1], t.e1[2], t.e2[0], t.e2[1]));
+					geom.push_back(make_float4(t.e2[2], as_float(ti), as_float(ni), 0.0f));
+					shade.push_back(make_float4(t.na[0], t.na[1], t.na[2], t.ta[0]));
+					shade.push_back(make_float4(t.nb[0], t.nb[1], t.nb[2], t.ta[1]));
+					shade.push_back(make_float4(t.nc[0], t.nc[1], t.nc[2], t.tb[0]));
+					shade.push_back(make_float4(t.tb[1], t.tc[0], t.tc[1], as_float(o.first_material + t.material)));
+				}
+				rec[3] = make_float4(as_float(-1), as_float(-1), as_float(first_dev), as_float(nd.num_tris));
+			} else {
+				float l[6] = {0, 0, 0, 0, 0, 0}, r[6] = {0, 0, 0, 0, 0, 0};
+				if (nd.left != -1) {
+					if (nd.left < 0 || nd.left >= o.num_nodes) return fail(PTX_E_INVALID, "object %d node %d: left child %d", oi, ni, nd.left);
+					for (int k = 0; k < 3; ++k) { l[k] = on[nd.left].bmin[k]; l[3 + k] = on[nd.left].bmax[k]; }
+					todo.push_back(std::make_pair(nd.left, dep + 1));
+				}
+				if (nd.right != -1) {
+					if (nd.right < 0 || nd.right >= o.num_nodes) return fail(PTX_E_INVALID, "object %d node %d: right child %d", oi, ni, nd.right);
+					for (int k = 0; k < 3; ++k) { r[k] = on[nd.right].bmin[k]; r[3 + k] = on[nd.right].bmax[k]; }
+					todo.push_back(std::make_pair(nd.right, dep + 1));
+				}
+				rec[0] = make_float4(l[0], l[1], l[2], l[3]);
+				rec[1] = make_float4(l[4], l[5], r[0], r[1]);
+				rec[2] = make_float4(r[2], r[3], r[4], r[5]);
+				rec[3] = make_float4(as_float(nd.left == -1 ? -1 : base + nd.left), as_float(nd.right == -1 ? -1 : base + nd.right),
+				                     as_float(0), as_float(0));
+			}
+		}
+		if (depth_max > scene_max_depth) scene_max_depth = depth_max;
+	}
+
+	HIP_TRY(hipSetDevice(ctx->device));
+	PtxScene* s = new PtxScene();
+	s->device = ctx->device;
+	s->bytes = 0;
+	s->num_objects = d->num_objects;
+	s->max_depth = scene_max_depth;
+	s->num_dev_triangles = (int)(geom.size() / 3);
+	memset(&s->dev, 0, sizeof(s->dev));
+	int rc;
+#define UP(vec, field) \
+	if ((rc = upload_vec(ctx, s, vec, &s->dev.field)) != PTX_OK) { free_scene_allocs(s); delete s; return rc; }
+	UP(objs, objects)
+	UP(nodes, nodes)
+	UP(geom, tri_geom)
+	UP(shade, tri_shade)
+	UP(mats, materials)
+#undef UP
+	std::vector<DevTexture> texs((size_t)d->num_textures);
+	for (int t = 0; t < d->num_textures; ++t) {
+		const PtxTexture& pt = d->textures[t];
+		size_t bytes = (size_t)pt.width * (size_t)pt.height * sizeof(float4);
+		void* dt = NULL;
+		hipError_t e = hipMalloc(&dt, bytes);
+		if (e != hipSuccess) { free_scene_allocs(s); delete s; return fail(PTX_E_HIP, "hipMalloc texture %d (%zu B): %s", t, bytes, hipGetErrorString(e)); }
+		s->allocs.push_back(dt);
+		s->bytes += (int64_t)bytes;
+		e = hipMemcpyAsync(dt, pt.rgba, bytes, hipMemcpyHostToDevice, ctx->stream);
+		if (e != hipSuccess) { free_scene_allocs(s); delete s; return fail(PTX_E_HIP, "hipMemcpy texture %d: %s", t, hipGetErrorString(e)); }
+		texs[(size_t)t].texels = (const float4*)dt;
+		texs[(size_t)t].width = pt.width;
+		texs[(size_t)t].height = pt.height;
+	}
+	if ((rc = upload_vec(ctx, s, texs, &s->dev.textures)) != PTX_OK) { free_scene_allocs(s); delete s; return rc; }
+	s->dev.num_objects = d->num_objects;
+	s->dev.stack_entries = scene_max_depth < 1 ? 1 : scene_max_depth;
+	hipError_t e = hipStreamSynchronize(ctx->stream); // host vectors die at return
+	if (e != hipSuccess) { free_scene_allocs(s); delete s; return fail(PTX_E_HIP, "scene upload: %s", hipGetErrorString(e)); }
+	*out = s;
+	return PTX_OK;
+}
+
+extern "C" int ptx_scene_free(PtxCtx* ctx, PtxScene* scene) {
+	if (!scene) return PTX_OK;
+	if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+	free_scene_allocs(scene);
+	delete scene;
+	return PTX_OK;
+}
+
+extern "C" int64_t ptx_scene_device_bytes(const PtxScene* scene) { return scene ? scene->bytes : 0; }
+
+// ---- render -----------------------------------------------------------------------------------
+
+static int fill_camera(const PtxCamera* c, DevCamera* d) {
+	if (c->width <= 0 || c->height <= 0) return fail(PTX_E_INVALID, "camera: resolution %dx%d", c->width, c->height);
+	if ((int64_t)c->width * (int64_t)c->height > (int64_t)1 << 28) return fail(PTX_E_LIMIT, "camera: more than 2^28 pixels");
+	if (c->max_ray_bounces < 0) return fail(PTX_E_INVALID, "camera: max_ray_bounces %d", c->max_ray_bounces);
+	for (int k = 0; k < 3; ++k) {
+		d->pos[k] = c->position[k]; d->dir[k] = c->direction[k]; d->up[k] = c->up[k]; d->right[k] = c->right[k];
+	}
+	d->width = c->width; d->height = c->height;
+	d->pixel_size = c->pixel_size;
+	d->half_x = c->screen_half[0]; d->half_y = c->screen_half[1];
+	d->screen_dist = c->screen_dist;
+	d->aa_jitter = c->aa_jitter;
+	d->max_bounces = c->max_ray_bounces;
+	d->preview_mode = c->preview_mode; d->aabb_mode = c->aabb_mode; d->texture_enabled = c->texture_enabled;
+	return PTX_OK;
+}
+
+extern "C" int ptx_render_init(PtxCtx* ctx, const PtxCamera* cam, void* external_accum) {
+	if (!ctx || !cam) return fail(PTX_E_INVALID, "ptx_render_init: NULL argument");
+	HIP_TRY(hipSetDevice(ctx->device));
+	if (ctx->has_render) ptx_render_cleanup(ctx);
+	int rc = fill_camera(cam, &ctx->cam);
+	if (rc != PTX_OK) return rc;
+	const size_t bytes = (size_t)cam->width * (size_t)cam->height * sizeof(float4);
+	if (external_accum) {
+		ctx->accum = (float4*)external_accum;
+		ctx->owns_accum = false;
+	} else {
+		HIP_TRY(hipMalloc((void**)&ctx->accum, bytes));
+		ctx->owns_accum = true;
+		HIP_TRY(hipMemsetAsync(ctx->accum, 0, bytes, ctx->stream));
+	}
+	ctx->has_render = true;
+	return PTX_OK;
+}
+
+extern "C" int ptx_render_set_camera(PtxCtx* ctx, const PtxCamera* cam) {
+	if (!ctx || !cam) return fail(PTX_E_INVALID, "ptx_render_set_camera: NULL argument");
+	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_render_set_camera before ptx_render_init");
+	if (cam->width != ctx->cam.width || cam->height != ctx->cam.height)
+		return fail(PTX_E_INVALID, "resolution change %dx%d -> %dx%d needs ptx_render_init", ctx->cam.width, ctx->cam.height, cam->width, cam->height);
+	return fill_camera(cam, &ctx->cam);
+}
+
+extern "C" int ptx_render_cleanup(PtxCtx* ctx) {
+	if (!ctx || !ctx->has_render) return PTX_OK;
+	hipSetDevice(ctx->device);
+	hipStreamSynchronize(ctx->stream);
+	if (ctx->owns_accum && ctx->accum) hipFree(ctx->accum);
+	ctx->accum = NULL;
+	ctx->owns_accum = false;
+	ctx->has_render = false;
+	return PTX_OK;
+}
+
+extern "C" int ptx_accum_clear(PtxCtx* ctx) {
+	if (!ctx || !ctx->has_render) return fail(PTX_E_STATE, "ptx_accum_clear before ptx_render_init");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipMemsetAsync(ctx->accum, 0, (size_t)ctx->cam.width * ctx->cam.height * sizeof(float4), ctx->stream));
+	return PTX_OK;
+}
+
+static size_t stack_lds_bytes(const PtxScene* s) { return (size_t)s->dev.stack_entries * PT_BLOCK * sizeof(int); }
+
+static int check_scene(const PtxCtx* ctx, const PtxScene* scene, const char* who) {
+	if (!ctx || !scene) return fail(PTX_E_INVALID, "%s: NULL argument", who);
+	if (scene->device != ctx->device) return fail(PTX_E_INVALID, "%s: scene lives on device %d, context on %d", who, scene->device, ctx->device);
+	if (stack_lds_bytes(scene) > 64 * 1024) return fail(PTX_E_LIMIT, "%s: traversal stack of %d levels does not fit LDS", who, scene->dev.stack_entries);
+	return PTX_OK;
+}
+
+extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
+                                  uint64_t seed, int collect_stats) {
+	int rc = check_scene(ctx, scene, "ptx_render_samples");
+	if (rc != PTX_OK) return rc;
+	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_render_samples before ptx_render_init");
+	if (first_sample < 0 || num_samples < 0 || (int64_t)first_sample + num_samples > 0x7fffffff)
+		return fail(PTX_E_INVALID, "sample range [%d,+%d)", first_sample, num_samples);
+	if (num_samples == 0) return PTX_OK;
+	HIP_TRY(hipSetDevice(ctx->device));
+	const int tiles_x = (ctx->cam.width + 15) / 16, tiles_y = (ctx->cam.height + 15) / 16;
+	const dim3 grid((unsigned)(tiles_x * tiles_y)), block(PT_BLOCK);
+	const size_t lds = stack_lds_bytes(scene);
+	const uint32_t k0 = (uint32_t)(seed & 0xffffffffu), k1 = (uint32_t)(seed >> 32);
+	if (ctx->cam.aabb_mode)
+		hipLaunchKernelGGL(render_kernel<PT_F_DEBUGMASK>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
+	else if (collect_stats)
+		hipLaunchKernelGGL(render_kernel<PT_F_STATS>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
+	else
+		hipLaunchKernelGGL(render_kernel<0>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
+	HIP_TRY(hipGetLastError());
+	return PTX_OK;
+}
+
+extern "C" int ptx_render_sync(PtxCtx* ctx) {
+	if (!ctx) return fail(PTX_E_INVALID, "ptx_render_sync: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" void* ptx_accum_device_ptr(PtxCtx* ctx) { return ctx ? (void*)ctx->accum : NULL; }
+
+extern "C" int ptx_accum_download(PtxCtx* ctx, float* rgba_host) {
+	if (!ctx || !rgba_host) return fail(PTX_E_INVALID, "ptx_accum_download: NULL argument");
+	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_accum_download before ptx_render_init");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipMemcpyAsync(rgba_host, ctx->accum, (size_t)ctx->cam.width * ctx->cam.height * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_accum_upload(PtxCtx* ctx, const float* rgba_host) {
+	if (!ctx || !rgba_host) return fail(PTX_E_INVALID, "ptx_accum_upload: NULL argument");
+	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_accum_upload before ptx_render_init");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipMemcpyAsync(ctx->accum, rgba_host, (size_t)ctx->cam.width * ctx->cam.height * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_tonemap(PtxCtx* ctx, int iter, float gamma, unsigned char* rgba8_host) {
+	if (!ctx || !rgba8_host) return fail(PTX_E_INVALID, "ptx_tonemap: NULL argument");
+	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_tonemap before ptx_render_init");
+	if (iter < 1) return fail(PTX_E_INVALID, "ptx_tonemap: iter %d < 1", iter);
+	HIP_TRY(hipSetDevice(ctx->device));
+	const size_t n = (size_t)ctx->cam.width * ctx->cam.height;
+	if (ctx->pbo_pixels < n) {
+		if (ctx->d_pbo) { HIP_TRY(hipStreamSynchronize(ctx->stream)); hipFree(ctx->d_pbo); ctx->d_pbo = NULL; ctx->pbo_pixels = 0; }
+		HIP_TRY(hipMalloc((void**)&ctx->d_pbo, n * sizeof(uchar4)));
+		ctx->pbo_pixels = n;
+	}
+	hipLaunchKernelGGL(tonemap_kernel, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream,
+	                   ctx->d_pbo, gamma, (int)n, iter, (const float4*)ctx->accum);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(rgba8_host, ctx->d_pbo, n * sizeof(uchar4), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_stats_get(PtxCtx* ctx, PtxStats* out) {
+	if (!ctx || !out) return fail(PTX_E_INVALID, "ptx_stats_get: NULL argument");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipMemcpyAsync(out, ctx->d_stats, sizeof(PtxStats), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_stats_reset(PtxCtx* ctx) {
+	if (!ctx) return fail(PTX_E_INVALID, "ptx_stats_reset: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipMemsetAsync(ctx->d_stats, 0, sizeof(PtxStats), ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_timer_begin(PtxCtx* ctx) {
+	if (!ctx) return fail(PTX_E_INVALID, "ptx_timer_begin: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+	ctx->timer_open = true;
+	return PTX_OK;
+}
+
+extern "C" int ptx_timer_end(PtxCtx* ctx, float* elapsed_ms) {
+	if (!ctx || !elapsed_ms) return fail(PTX_E_INVALID, "ptx_timer_end: NULL argument");
+	if (!ctx->timer_open) return fail(PTX_E_STATE, "ptx_timer_end without ptx_timer_begin");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+	HIP_TRY(hipEventSynchronize(ctx->ev1));
+	HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+	ctx->timer_open = false;
+	return PTX_OK;
+}
+
+// ---- parity entry points ------------------------------------------------------------------------
+
+struct DevBuf {
+	void* p;
+	DevBuf() : p(NULL) {}
+	~DevBuf() { if (p) hipFree(p); }
+};
+
+extern "C" int ptx_trace_rays(PtxCtx* ctx, const PtxScene* scene, int n, const float* origins, const float* dirs,
+                              int object, PtxHit* hits_host) {
+	int rc = check_scene(ctx, scene, "ptx_trace_rays");
+	if (rc != PTX_OK) return rc;
+	if (n < 0 || (n > 0 && (!origins || !dirs || !hits_host))) return fail(PTX_E_INVALID, "ptx_trace_rays: bad ray arrays");
+	if (object < -1 || object >= scene->num_objects) return fail(PTX_E_INVALID, "ptx_trace_rays: object %d outside [-1,%d)", object, scene->num_objects);
+	if (n == 0) return PTX_OK;
+	HIP_TRY(hipSetDevice(ctx->device));
+	DevBuf d_o, d_d, d_h;
+	const size_t rb = (size_t)n * 3 * sizeof(float);
+	HIP_TRY(hipMalloc(&d_o.p, rb));
+	HIP_TRY(hipMalloc(&d_d.p, rb));
+	HIP_TRY(hipMalloc(&d_h.p, (size_t)n * sizeof(PtxHit)));
+	HIP_TRY(hipMemcpyAsync(d_o.p, origins, rb, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(d_d.p, dirs, rb, hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(trace_kernel, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), stack_lds_bytes(scene), ctx->stream,
+	                   scene->dev, n, (const float*)d_o.p, (const float*)d_d.p, object, (PtxHit*)d_h.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(hits_host, d_h.p, (size_t)n * sizeof(PtxHit), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_generate_rays(PtxCtx* ctx, const PtxCamera* cam, int sample, uint64_t seed, float* origins_host,
+                                 float* dirs_host) {
+	if (!ctx || !cam || !origins_host || !dirs_host) return fail(PTX_E_INVALID, "ptx_generate_rays: NULL argument");
+	DevCamera dc;
+	int rc = fill_camera(cam, &dc);
+	if (rc != PTX_OK) return rc;
+	HIP_TRY(hipSetDevice(ctx->device));
+	const size_t n = (size_t)cam->width * cam->height;
+	DevBuf d_o, d_d;
+	HIP_TRY(hipMalloc(&d_o.p, n * 3 * sizeof(float)));
+	HIP_TRY(hipMalloc(&d_d.p, n * 3 * sizeof(float)));
+	hipLaunchKernelGGL(genrays_kernel, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, dc, sample,
+	                   (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), (float*)d_o.p, (float*)d_d.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(origins_host, d_o.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(dirs_host, d_d.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_bsdf_eval(PtxCtx* ctx, int n, PtxBsdfCase* cases_host) {
+	if (!ctx || n < 0 || (n > 0 && !cases_host)) return fail(PTX_E_INVALID, "ptx_bsdf_eval: bad arguments");
+	if (n == 0) return PTX_OK;
+	for (int i = 0; i < n; ++i)
+		if (cases_host[i].mat_type < 0 || cases_host[i].mat_type > 3) return fail(PTX_E_INVALID, "ptx_bsdf_eval: case %d material type %d", i, cases_host[i].mat_type);
+	HIP_TRY(hipSetDevice(ctx->device));
+	DevBuf d_c;
+	HIP_TRY(hipMalloc(&d_c.p, (size_t)n * sizeof(PtxBsdfCase)));
+	HIP_TRY(hipMemcpyAsync(d_c.p, cases_host, (size_t)n * sizeof(PtxBsdfCase), hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(bsdf_kernel, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, n, (PtxBsdfCase*)d_c.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(cases_host, d_c.p, (size_t)n * sizeof(PtxBsdfCase), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_radiance_sample(PtxCtx* ctx, const PtxScene* scene, int sample, uint64_t seed, float* rgb_host) {
+	int rc = check_scene(ctx, scene, "ptx_radiance_sample");
+	if (rc != PTX_OK) return rc;
+	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_radiance_sample before ptx_render_init");
+	if (!rgb_host || sample < 0) return fail(PTX_E_INVALID, "ptx_radiance_sample: bad arguments");
+	HIP_TRY(hipSetDevice(ctx->device));
+	const size_t n = (size_t)ctx->cam.width * ctx->cam.height;
+	DevBuf tmp;
+	HIP_TRY(hipMalloc(&tmp.p, n * sizeof(float4)));
+	HIP_TRY(hipMemsetAsync(tmp.p, 0, n * sizeof(float4), ctx->stream));
+	float4* saved = ctx->accum;
+	ctx->accum = (float4*)tmp.p;
+	rc = ptx_render_samples(ctx, scene, sample, 1, seed, 0);
+	ctx->accum = saved;
+	if (rc != PTX_OK) return rc;
+	std::vector<float> host(n * 4);
+	HIP_TRY(hipMemcpyAsync(host.data(), tmp.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	for (size_t i = 0; i < n; ++i) {
+		rgb_host[3 * i] = host[4 * i]; rgb_host[3 * i + 1] = host[4 * i + 1]; rgb_host[3 * i + 2] = host[4 * i + 2];
+	}
+	return PTX_OK;
+}

@@ -1,0 +1,54 @@
+/*
+ * host_capi.h — plain-C window onto the C++ host layer (scene JSON -> loader -> KD build ->
+ * render calls with the reference's entry-point names), for the ctypes harness and bench.py.
+ * These forward to the functions in world_load.h / scenestate.h / kernel.h; they add no logic.
+ */
+#ifndef PT_HOST_CAPI_H
+#define PT_HOST_CAPI_H
+#include "../../include/ptx_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* pth_last_error(void);
+void pth_set_asset_root(const char* dir);
+void pth_set_device(int device);
+void pth_set_device_upload(int enabled);            /* 0: host-side load only (CPU tests) */
+void pth_set_procedural_car_triangles(int n);
+void pth_set_seed(uint64_t seed);
+
+/* parseJsonScene + sceneState.load (reference: qt/sceneloaderthread.cpp:11-23); width/height > 0
+ * force the resolution, textures/preview/aabb/bounces < 0 keep the Camera::init defaults except
+ * that preview_mode defaults to OFF here (the GUI's "normal" radio, qt/mainwindow.cpp:244-250). */
+int pth_scene_load(const char* json_path, int width, int height, int textures, int preview, int aabb, int bounces);
+int pth_scene_free(void);
+int pth_scene_is_loaded(void);
+const PtxSceneDesc* pth_scene_desc(void);            /* what ptx_scene_upload received */
+const float* pth_scene_tri_abc(void);                /* 9 floats per triangle (a, b, c) */
+PtxScene* pth_scene_device(void);
+int pth_camera_get(PtxCamera* out);
+int pth_camera_control(const char* what, float value); /* "h_ang","v_ang","pos_x","pos_y","pos_z","reset","bounces","aa_jitter","gamma","preview","aabb","textures" */
+int pth_log_lines(char* buf, int buf_len);
+
+/* kernel.h */
+PtxCtx* pth_context(void);
+int pth_kernel_init(void);                             /* kernelInit(sceneState.clone()) */
+int pth_run_iteration(int iter, unsigned char* pbo_rgba8); /* runCUDA(pbo, scene, iter) */
+int pth_render_samples(int first_sample, int num_samples, int collect_stats);
+int pth_kernel_cleanup(void);
+void pth_shutdown(void);
+
+/* KD build on caller triangles (buildKDTree + flatenKDTree); outputs malloc'ed, release with pth_free */
+int pth_kd_build(const float* abc, int n, PtxKDNode** nodes_out, int32_t** leaf_tris_out, int* num_leaf_tris_out, int* max_depth_out);
+void pth_free(void* p);
+float pth_fmedian(float* arr, int n);
+
+/* image helpers */
+int pth_load_image_float(const char* path, int* w, int* h, int* channels, float** pixels_out);
+int pth_write_png(const char* path, int w, int h, int comp, const unsigned char* pixels, int mirror_h);
+int pth_write_pfm(const char* path, int w, int h, const float* rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,120 @@
+// Render boundary over the C ABI (reference: src/kernel.cu:22-103).
+#include "kernel.h"
+
+#include <cstdio>
+#include <cstring>
+
+int hip_device_id = 0;
+
+uchar4* pbo_dptr = NULL;
+float4* device_accum_image = NULL;
+
+static PtxCtx* g_ctx = NULL;
+static uint64_t g_seed = 0;
+static int g_last_status = PTX_OK;
+static bool g_render_ready = false;
+
+PtxCtx* kernelContext() {
+	if (!g_ctx) {
+		if (ptx_ctx_create(hip_device_id, &g_ctx) != PTX_OK) {
+			fprintf(stderr, "\n>  HIP RESULT FAIL: %s\n\n", ptx_last_error());
+			g_ctx = NULL;
+		}
+	}
+	return g_ctx;
+}
+
+void kernelShutdown() {
+	if (g_ctx) { ptx_ctx_destroy(g_ctx); g_ctx = NULL; }
+	g_render_ready = false;
+}
+
+void kernelSetSeed(uint64_t seed) { g_seed = seed; }
+uint64_t kernelSeed() { return g_seed; }
+
+void fillPtxCamera(const Camera& cam, PtxCamera* out) {
+	memset(out, 0, sizeof(*out));
+	const float3* src[4] = {&cam.position, &cam.direction, &cam.up, &cam.right};
+	float* dst[4] = {out->position, out->direction, out->up, out->right};
+	for (int i = 0; i < 4; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+	out->width = cam.projection.width;
+	out->height = cam.projection.height;
+	out->pixel_size = cam.projection.pixel_size.x;
+	out->screen_half[0] = cam.projection.screen_halfsize.x;
+	out->screen_half[1] = cam.projection.screen_halfsize.y;
+	out->screen_dist = cam.projection.screen_dist;
+	out->aa_jitter = cam.projection.aa_jitter;
+	out->gamma_corr = cam.projection.gamma_corr;
+	out->max_ray_bounces = cam.max_ray_bounces;
+	out->preview_mode = cam.preview_mode ? 1 : 0;
+	out->aabb_mode = cam.aabb_mode ? 1 : 0;
+	out->texture_enabled = cam.texture_enabled ? 1 : 0;
+}
+
+// reference: src/kernel.cu:22-28 kernelInit (+ initPathTracing, src/pathtracing.cu:44-62)
+void kernelInit(const Scene& scene) {
+	PtxCtx* ctx = kernelContext();
+	if (!ctx) { g_last_status = PTX_E_NO_DEVICE; return; }
+	PtxCamera pc;
+	fillPtxCamera(scene.camera, &pc);
+	g_last_status = ptx_render_init(ctx, &pc, NULL);
+	g_render_ready = g_last_status == PTX_OK;
+	device_accum_image = (float4*)ptx_accum_device_ptr(ctx);
+	if (!g_render_ready) fprintf(stderr, "\n>  HIP RESULT FAIL: %s\n\n", ptx_last_error());
+}
+
+// reference: src/kernel.cu:30-35
+void kernelCleanUp() {
+	if (g_ctx) ptx_render_cleanup(g_ctx);
+	device_accum_image = NULL;
+	g_render_ready = false;
+}
+
+int renderSamples(Scene& scene, int first_sample, int num_samples, bool collect_stats) {
+	PtxCtx* ctx = kernelContext();
+	if (!ctx || !g_render_ready) return g_last_status = PTX_E_STATE;
+	if (scene.camera.changed) {
+		// reference: src/pathtracing.cu:166-172 — camera changed: regenerate primary rays
+		PtxCamera pc;
+		fillPtxCamera(scene.camera, &pc);
+		int rc = ptx_render_set_camera(ctx, &pc);
+		if (rc != PTX_OK) return g_last_status = rc;
+		scene.camera.changed = false;
+	}
+	return g_last_status = ptx_render_samples(ctx, (const PtxScene*)scene.dv_wobjects_ptr, first_sample, num_samples, g_seed,
+	                                          collect_stats ? 1 : 0);
+}
+
+// reference: src/kernel.cu:59-91 kernelMain: iteration `iter` (1-based) = global sample iter-1
+int kernelMain(uchar4* pbo, Scene& scene, int iter) {
+	PtxCtx* ctx = kernelContext();
+	if (!ctx || !g_render_ready) return g_last_status = PTX_E_STATE;
+	if (iter < 1) return g_last_status = PTX_E_INVALID;
+	if (iter == 1) {
+		int rc = ptx_accum_clear(ctx); // :69-72
+		if (rc != PTX_OK) return g_last_status = rc;
+	}
+	int rc = renderSamples(scene, iter - 1, 1, false);
+	if (rc != PTX_OK) return rc;
+	// :83-88 writeImageToPBO
+	rc = ptx_tonemap(ctx, iter, scene.camera.projection.gamma_corr, (unsigned char*)pbo);
+	return g_last_status = rc;
+}
+
+// reference: src/kernel.cu:94-103
+void runCUDA(uchar4* pbo, Scene& scene, int iter) {
+	if (pbo)
+		kernelMain(pbo, scene, iter);
+	else {
+		printf("Failed to map pbo pointer.\n");
+		g_last_status = PTX_E_INVALID;
+	}
+}
+
+bool checkCudaError(const char* context) {
+	if (g_last_status != PTX_OK) {
+		fprintf(stderr, "HIP error in %s: %s\n", context, ptx_last_error());
+		return true;
+	}
+	return false;
+}

@@ -1,0 +1,118 @@
+// Headless driver: the reference's render thread (reference: qt/cudarunthread.cpp:14-56) and
+// scene loader thread (qt/sceneloaderthread.cpp:11-23) as a command-line program.
+//   pt_render --scene scenes/scene_geoms.json [--width W --height H] [--spp N] [--bounces B]
+//             [--textures 0|1] [--seed S] [--device D] [--batch K] [--out image.png] [--pfm image.pfm]
+//             [--assets DIR] [--car-tris N] [--iterate]
+// --iterate drives runCUDA() once per sample exactly like the reference loop (tonemap every
+// iteration); the default renders the samples in batches of K per launch.
+#include "kernel.h"
+#include "scenestate.h"
+#include "world_load.h"
+#include "image_io.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+int main(int argc, char** argv) {
+	std::string scene_path, out_png, out_pfm, assets;
+	int width = 0, height = 0, spp = 16, bounces = -1, textures = -1, batch = 16, car_tris = 0;
+	unsigned long long seed = 0;
+	bool iterate = false;
+	for (int i = 1; i < argc; ++i) {
+		std::string a = argv[i];
+		auto next = [&](const char* what) -> const char* {
+			if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", what); exit(2); }
+			return argv[++i];
+		};
+		if (a == "--scene") scene_path = next("--scene");
+		else if (a == "--width") width = atoi(next("--width"));
+		else if (a == "--height") height = atoi(next("--height"));
+		else if (a == "--spp") spp = atoi(next("--spp"));
+		else if (a == "--bounces") bounces = atoi(next("--bounces"));
+		else if (a == "--textures") textures = atoi(next("--textures"));
+		else if (a == "--seed") seed = strtoull(next("--seed"), NULL, 10);
+		else if (a == "--device") hip_device_id = atoi(next("--device"));
+		else if (a == "--batch") batch = atoi(next("--batch"));
+		else if (a == "--out") out_png = next("--out");
+		else if (a == "--pfm") out_pfm = next("--pfm");
+		else if (a == "--assets") assets = next("--assets");
+		else if (a == "--car-tris") car_tris = atoi(next("--car-tris"));
+		else if (a == "--iterate") iterate = true;
+		else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+	}
+	if (scene_path.empty()) { fprintf(stderr, "usage: pt_render --scene file.json [options]\n"); return 2; }
+	printProgramConfig();
+	if (detectHIPdevice() < 0) return 1;
+	if (!assets.empty()) setAssetRoot(assets);
+	if (car_tris > 0) setProceduralCarTriangles(car_tris);
+	kernelSetSeed(seed);
+
+	Json::Value jscene;
+	std::string err;
+	if (!parseJsonScene(scene_path, jscene, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+	DialogLogger logger(stdout);
+	if (!sceneState.load(jscene, &logger)) return 1;
+	if (width > 0 && height > 0) sceneState.overrideResolution(width, height);
+	sceneState.togglePrevMode(false);
+	sceneState.toggleAABBmode(false);
+	if (textures >= 0) sceneState.toggleTextures(textures != 0);
+	if (bounces >= 0) sceneState.updateMaxRayBnc(bounces);
+
+	Scene scene = sceneState.clone();
+	sceneState.cameraChanged(false, NULL);
+	scene.camera.changed = false;
+	const int W = scene.camera.projection.width, H = scene.camera.projection.height;
+	std::vector<uchar4> pbo((size_t)W * H);
+	pbo_dptr = pbo.data();
+	kernelInit(scene);
+	if (checkCudaError("kernelInit")) return 1;
+
+	PtxCtx* ctx = kernelContext();
+	auto t0 = std::chrono::steady_clock::now();
+	if (iterate) {
+		for (int i = 1; i <= spp; ++i) {
+			runCUDA(pbo_dptr, scene, i);
+			if (checkCudaError("runCUDA")) return 1;
+		}
+	} else {
+		ptx_accum_clear(ctx);
+		for (int s = 0; s < spp; s += batch) {
+			int n = spp - s < batch ? spp - s : batch;
+			if (renderSamples(scene, s, n, false) != PTX_OK) { fprintf(stderr, "%s\n", ptx_last_error()); return 1; }
+		}
+		ptx_render_sync(ctx);
+		ptx_tonemap(ctx, spp, scene.camera.projection.gamma_corr, (unsigned char*)pbo.data());
+	}
+	double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	PtxStats st;
+	ptx_stats_get(ctx, &st);
+	printf("rendered %dx%d, %d spp in %.3f s: %.1f Mrays/s, %.2f Msamples/s\n", W, H, spp, sec, st.rays / sec * 1e-6,
+	       (double)W * H * spp / sec * 1e-6);
+
+	if (!out_png.empty()) {
+		// on-screen orientation of the reference: buffer mirrored horizontally, alpha opaque
+		std::vector<unsigned char> rgb((size_t)W * H * 3);
+		for (int y = 0; y < H; ++y)
+			for (int x = 0; x < W; ++x) {
+				const uchar4& p = pbo[(size_t)y * W + (W - 1 - x)];
+				unsigned char* o = &rgb[((size_t)y * W + x) * 3];
+				o[0] = p.x; o[1] = p.y; o[2] = p.z;
+			}
+		if (!writePNG(out_png, W, H, 3, rgb.data(), err)) fprintf(stderr, "%s\n", err.c_str());
+	}
+	if (!out_pfm.empty()) {
+		std::vector<float> acc((size_t)W * H * 4), rgbf((size_t)W * H * 3);
+		ptx_accum_download(ctx, acc.data());
+		for (size_t i = 0; i < (size_t)W * H; ++i)
+			for (int k = 0; k < 3; ++k) rgbf[3 * i + k] = acc[4 * i + k] / (float)spp;
+		if (!writePFM(out_pfm, W, H, rgbf.data(), err)) fprintf(stderr, "%s\n", err.c_str());
+	}
+	kernelCleanUp();
+	sceneState.clean();
+	kernelShutdown();
+	return 0;
+}

@@ -1,0 +1,114 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so) and the reference-built pin library
+(oracle/_ref/libref_host.so). TEST INFRASTRUCTURE: imported only by tests/, smoke() and bench.py's
+cpu_baseline leg."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pt = importlib.import_module("path-tracer_amd")
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle.so not built: run `make -C oracle`")
+        L = C.CDLL(path)
+        fp, i32, u64 = C.POINTER(C.c_float), C.c_int, C.c_uint64
+        L.orc_fmedian.argtypes = [fp, i32]
+        L.orc_fmedian.restype = C.c_float
+        L.orc_kd_build.argtypes = [fp, i32, C.POINTER(C.POINTER(pt.PtxKDNode)), C.POINTER(C.POINTER(C.c_int32)),
+                                   C.POINTER(i32), C.POINTER(i32)]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_trace_rays.argtypes = [C.POINTER(pt.PtxSceneDesc), i32, fp, fp, i32, C.POINTER(pt.PtxHit)]
+        L.orc_generate_rays.argtypes = [C.POINTER(pt.PtxCamera), i32, u64, fp, fp]
+        L.orc_bsdf_eval.argtypes = [i32, C.POINTER(pt.PtxBsdfCase)]
+        L.orc_radiance_sample.argtypes = [C.POINTER(pt.PtxSceneDesc), C.POINTER(pt.PtxCamera), i32, u64, fp, i32]
+        L.orc_render.argtypes = [C.POINTER(pt.PtxSceneDesc), C.POINTER(pt.PtxCamera), i32, i32, u64, fp, i32,
+                                 C.POINTER(pt.PtxStats)]
+        L.orc_tonemap.argtypes = [fp, i32, i32, C.c_float, C.POINTER(C.c_ubyte)]
+        L.orc_wang_hash.argtypes = [C.c_uint32]
+        L.orc_wang_hash.restype = C.c_uint32
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_u01.argtypes = [C.c_uint32]
+        L.orc_u01.restype = C.c_float
+        L.orc_sincos.argtypes = [C.c_float, fp, fp]
+        L.orc_acos01.argtypes = [C.c_float]
+        L.orc_acos01.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def ref():
+    """oracle/_ref/libref_host.so (reference sources compiled unchanged) or None if not built."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libref_host.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        fp = C.POINTER(C.c_float)
+        R.ref_fmedian.argtypes = [fp, C.c_int]
+        R.ref_fmedian.restype = C.c_float
+        R.ref_camera_init.argtypes = [C.c_char_p, fp, C.POINTER(C.c_int)]
+        R.ref_camera_rotate.argtypes = [C.c_char_p, C.c_float, C.c_float, fp, fp]
+        R.ref_resolve.argtypes = [C.c_char_p, C.c_char_p, fp, fp, C.POINTER(C.c_int)]
+        _ref = R
+    return _ref
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def hits_to_arrays(hits, n):
+    """PtxHit array -> dict of numpy arrays (bit patterns for floats)."""
+    buf = np.frombuffer(hits, dtype=np.uint8).reshape(n, C.sizeof(pt.PtxHit))
+    u32 = buf.view(np.uint32).reshape(n, -1)
+    names = ["hit", "object", "prim", "t_bits", "leaf_hash", "n_inner", "n_box", "n_tri", "n_leaf"]
+    out = {k: u32[:, i].copy() for i, k in enumerate(names)}
+    out["point"] = u32[:, 9:12].copy()
+    out["normal"] = u32[:, 12:15].copy()
+    out["bary"] = u32[:, 15:18].copy()
+    return out
+
+
+def trace(desc, origins, dirs, obj=-1):
+    n = origins.shape[0]
+    hits = (pt.PtxHit * n)()
+    o = np.ascontiguousarray(origins, np.float32)
+    d = np.ascontiguousarray(dirs, np.float32)
+    rc = lib().orc_trace_rays(desc, n, fptr(o), fptr(d), obj, hits)
+    assert rc == 0
+    return hits_to_arrays(hits, n)
+
+
+def generate_rays(cam, sample, seed):
+    n = cam.width * cam.height
+    o = np.empty((n, 3), np.float32)
+    d = np.empty((n, 3), np.float32)
+    assert lib().orc_generate_rays(C.byref(cam), sample, seed, fptr(o), fptr(d)) == 0
+    return o, d
+
+
+def render(desc, cam, first, count, seed, accum=None, nthreads=0):
+    n = cam.width * cam.height
+    if accum is None:
+        accum = np.zeros((n, 4), np.float32)
+    st = pt.PtxStats()
+    assert lib().orc_render(desc, C.byref(cam), first, count, seed, fptr(accum), nthreads, C.byref(st)) == 0
+    return accum, st
+
+
+def radiance_sample(desc, cam, sample, seed, nthreads=0):
+    n = cam.width * cam.height
+    rgb = np.empty((n, 3), np.float32)
+    assert lib().orc_radiance_sample(desc, C.byref(cam), sample, seed, fptr(rgb), nthreads) == 0
+    return rgb

@@ -1,0 +1,135 @@
+"""GPU parity: HIP path vs the CPU oracle on the same seeded inputs, through the C ABI.
+Bar: bit-exact (traversal, hit ids, leaf visits, ray generation, BSDFs, radiance, accumulation)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gpuops
+
+pytestmark = pytest.mark.gpu
+
+SCENES = ["example", "geoms", "teapot", "sky_map"]
+
+
+def _secondary_rays(orc_hits, origins, dirs, rng, n):
+    """Rays leaving surfaces in random directions (incoherent), plus axis-parallel ones with inf inverses."""
+    hit = orc_hits["hit"] == 1
+    pts = orc_hits["point"].view(np.float32)[hit]
+    idx = rng.integers(0, len(pts), n)
+    o = pts[idx] + rng.normal(0, 1e-3, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    axis = np.eye(3, dtype=np.float32)
+    d[:6] = np.concatenate([axis, -axis])
+    d[6:9, :] = axis * np.float32(1.0)
+    d[6:9, :] += np.roll(axis, 1, axis=1) * np.float32(0.5)  # one zero component
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_trace_bit_exact(pt, orc, ctx, name):
+    desc, cam = pt.load_scene(name, width=160, height=120, textures=1)
+    scene = pt.host().pth_scene_device()
+    o, d = orc.generate_rays(cam, -1, 0)
+    ho = orc.trace(desc, o, d)
+    hg = gpuops.trace(ctx, scene, o, d)
+    for k in ho:
+        assert np.array_equal(ho[k], hg[k]), f"{name}: primary rays differ in {k}"
+    assert ho["hit"].sum() > 0
+    rng = np.random.default_rng(1234)
+    o2, d2 = _secondary_rays(ho, o, d, rng, 8192)
+    ho2 = orc.trace(desc, o2, d2)
+    hg2 = gpuops.trace(ctx, scene, o2, d2)
+    for k in ho2:
+        assert np.array_equal(ho2[k], hg2[k]), f"{name}: secondary rays differ in {k}"
+    # per-object queries (rayIntersectsObject)
+    for obj in range(desc.contents.num_objects):
+        a = orc.trace(desc, o2[:2048], d2[:2048], obj)
+        b = gpuops.trace(ctx, scene, o2[:2048], d2[:2048], obj)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), f"{name}: object {obj} differs in {k}"
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_generate_rays_bit_exact(pt, orc, ctx, name):
+    desc, cam = pt.load_scene(name, width=96, height=64, upload=True)
+    for sample in (-1, 0, 7):
+        oo, od = orc.generate_rays(cam, sample, 99)
+        go, gd = gpuops.generate_rays(ctx, cam, sample, 99)
+        assert np.array_equal(oo.view(np.uint32), go.view(np.uint32))
+        assert np.array_equal(od.view(np.uint32), gd.view(np.uint32)), f"sample {sample}"
+
+
+def test_bsdf_bit_exact(pt, orc, ctx):
+    rng = np.random.default_rng(7)
+    n = 4096
+    cases = (pt.PtxBsdfCase * n)()
+    for i in range(n):
+        c = cases[i]
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        if i % 16 == 0:
+            nrm = np.array([0.0, 0.0, 1.0 if i % 32 else -1.0])  # degenerate ONB branch
+        if i % 16 == 1:
+            d = -nrm  # normal incidence
+        c.dir[:] = d.astype(np.float32); c.normal[:] = nrm.astype(np.float32)
+        c.point[:] = rng.normal(size=3).astype(np.float32)
+        c.mat_type = 1 + i % 3
+        c.reflect_factor = float(rng.random()); c.refract_index = float(1.0 + rng.random())
+        c.sharpness = float(rng.random())
+        c.u[:] = ((rng.integers(0, 1 << 24, 4) + 1) / float(1 << 24)).astype(np.float32)
+    ref = (pt.PtxBsdfCase * n)()
+    C.memmove(ref, cases, C.sizeof(cases))
+    assert orc.lib().orc_bsdf_eval(n, ref) == 0
+    pt.check(pt.lib().ptx_bsdf_eval(ctx, n, cases))
+    a = np.frombuffer(ref, dtype=np.uint32).reshape(n, -1)
+    b = np.frombuffer(cases, dtype=np.uint32).reshape(n, -1)
+    bad = np.nonzero((a != b).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} BSDF cases differ, first {bad[:5]}"
+
+
+@pytest.mark.parametrize("name,tex", [("example", 0), ("geoms", 0), ("teapot", 0), ("sky_map", 1)])
+def test_radiance_and_accumulation_bit_exact(pt, orc, ctx, name, tex):
+    desc, cam = pt.load_scene(name, width=64, height=48, textures=tex)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    for s in (0, 5):
+        ro = orc.radiance_sample(desc, cam, s, 42)
+        rg = gpuops.radiance_sample(ctx, scene, cam, s, 42)
+        assert np.array_equal(ro.view(np.uint32), rg.view(np.uint32)), f"{name}: radiance of sample {s} differs"
+    acc_o, st_o = orc.render(desc, cam, 0, 8, 42)
+    acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 8, 42, stats=True)
+    assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32)), f"{name}: accumulation differs"
+    # one launch of 8 samples == 8 launches of 1 sample == reference schedule
+    acc_g1, _ = gpuops.render(ctx, scene, cam, 0, 8, 42, batch=1)
+    assert np.array_equal(acc_g.view(np.uint32), acc_g1.view(np.uint32))
+    for k in ("rays", "paths", "n_inner", "n_box", "n_tri", "n_sphere", "n_leaf", "hit_mesh", "hit_sphere", "hit_textured"):
+        assert getattr(st_o, k) == getattr(st_g, k), f"{name}: counter {k}: oracle {getattr(st_o, k)} gpu {getattr(st_g, k)}"
+    assert acc_o[:, :3].max() > 0
+
+
+def test_preview_and_aabb_modes(pt, orc, ctx):
+    for kw in ({"preview": 1}, {"aabb": 1}):
+        desc, cam = pt.load_scene("teapot", width=64, height=48, **kw)
+        scene = pt.host().pth_scene_device()
+        gpuops.render_init(ctx, cam)
+        acc_o, _ = orc.render(desc, cam, 0, 2, 3)
+        acc_g, _ = gpuops.render(ctx, scene, cam, 0, 2, 3)
+        assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32)), kw
+        assert acc_o[:, :3].max() > 0
+
+
+def test_tonemap_matches_oracle(pt, orc, ctx):
+    desc, cam = pt.load_scene("geoms", width=64, height=48)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc, _ = gpuops.render(ctx, scene, cam, 0, 4, 1)
+    n = cam.width * cam.height
+    out_g = np.empty((n, 4), np.uint8)
+    pt.check(pt.lib().ptx_tonemap(ctx, 4, 0.5, out_g.ctypes.data_as(C.POINTER(C.c_ubyte))))
+    out_o = np.empty((n, 4), np.uint8)
+    assert orc.lib().orc_tonemap(orc.fptr(acc), n, 4, 0.5, out_o.ctypes.data_as(C.POINTER(C.c_ubyte))) == 0
+    # powf differs by at most 1 ulp between libm and the device library: allow 1 LSB on truncation
+    assert np.abs(out_g.astype(int) - out_o.astype(int)).max() <= 1
+    assert (out_g[:, 3] == 0).all()
