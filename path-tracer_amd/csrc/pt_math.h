@@ -36,9 +36,12 @@ PT_DEV float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_DEV f3 cross3(f3 a, f3 b) {
 	return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-PT_DEV float length3(f3 v) { return __fsqrt_rn(dot3(v, v)); }
+// IEEE correctly-rounded square root. NOTE: HIP's __fsqrt_rn() lowers to a bare v_sqrt_f32
+// (about 1 ulp) on gfx950 with ROCm 7.2; __builtin_sqrtf gets the compiler's fix-up sequence.
+PT_DEV float pt_sqrt(float x) { return __builtin_sqrtf(x); }
+PT_DEV float length3(f3 v) { return pt_sqrt(dot3(v, v)); }
 PT_DEV f3 normalize3(f3 v) {
-	float invLen = 1.0f / __fsqrt_rn(dot3(v, v));
+	float invLen = 1.0f / pt_sqrt(dot3(v, v));
 	return v * invLen;
 }
 PT_DEV f3 reflect3(f3 i, f3 n) { return i - (2.0f * n) * dot3(n, i); }
@@ -87,7 +90,7 @@ PT_DEV float pt_acos01(float x) {
 	if (x > 1.0f) x = 1.0f;
 	if (x > 0.5f) {
 		float z = 0.5f * (1.0f - x);
-		float sq = __fsqrt_rn(z);
+		float sq = pt_sqrt(z);
 		float p = 4.2163199048e-2f;
 		p = p * z + 2.4181311049e-2f;
 		p = p * z + 4.5470025998e-2f;

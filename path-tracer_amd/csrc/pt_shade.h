@@ -23,14 +23,14 @@ PT_DEV f3 rand_cone_dir(f3 axis, float ang_max_dev, UniformStream& rs) {
 	f3 u = normalize3((axis.x != 0.0f || axis.y != 0.0f) ? mk3(axis.y, -axis.x, 0.0f) : mk3(0.0f, axis.z, -axis.y));
 	f3 v = normalize3(cross3(u, axis));
 	const float r2 = pt_sin(ang_max_dev) * rs.draw();
-	const float r = __fsqrt_rn(r2);
+	const float r = pt_sqrt(r2);
 	const float theta = PT_PI_X2 * rs.draw();
 	float sinth, costh;
 	pt_sincos(theta, &sinth, &costh);
 	// reference :18,31 — EPS is the double literal 0.0001, so the sum is formed in double and
 	// rounded to float once when passed to __fsqrt_rn
 	const float w2 = (float)((double)(1.0f - r2) + 0.0001);
-	return normalize3((sinth * r) * u + (costh * r) * v + __fsqrt_rn(w2) * axis);
+	return normalize3((sinth * r) * u + (costh * r) * v + pt_sqrt(w2) * axis);
 }
 
 // reference: src/surfaces.cuh:37-44 Diffuse_BRDF
@@ -66,7 +66,7 @@ PT_DEV void refractive_brdf(Ray& ray, float n_obj, float refl_factor, f3& mask, 
 		// total internal reflection
 		init_ray(ray, ip + n_or * REFL_BIAS, reflect3(ray.d, n_or));
 	} else {
-		float cosrefr = __fsqrt_rn(cos2refr);
+		float cosrefr = pt_sqrt(cos2refr);
 		f3 trans = normalize3(ray.d * nn - n * ((outside ? 1.0f : -1.0f) * (cos_ray * nn + cosrefr)));
 		float ndiff = n_obj - N_SCENE;
 		float nsum = n_obj + N_SCENE;

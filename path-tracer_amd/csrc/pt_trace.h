@@ -90,7 +90,7 @@ PT_DEV bool sphere_test(const Ray& r, float rad, f3 center, f3& hit_point, f3& h
 	float b = dot3(op, r.d);
 	float disc = b * b - dot3(op, op) + rad * rad;
 	if (disc < 0.0f) return false;
-	disc = __fsqrt_rn(disc);
+	disc = pt_sqrt(disc);
 	float t = b - disc;
 	if (t < epsilon) t = b + disc;
 	if (t < epsilon) return false;
