@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (whole job) on the Lamborghini scene at 1920x1080.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: SPP_PER_STEP samples of every pixel
+(jittered primary ray -> KD traversal / intersection -> BSDF bounce loop -> accumulation), i.e.
+what SPP_PER_STEP calls of the reference's runCUDA() do. Inputs (scene, textures, accumulation
+buffer) are resident in HBM before the timed region. With N > 1 (torchrun, one rank per GPU)
+every rank renders its own disjoint sample range per step (weak scaling, no data-path
+collective) and ONE all-reduce (RCCL) of the float accumulation buffers closes the timed region.
+
+Prints one JSON line (rank 0) with the contract fields plus
+  "roofline"      for the dominant kernel, render_kernel: algorithmic bytes per launch (DESIGN.md
+                  "bytes per ray", counters measured on the same samples by the counting variant)
+                  / mean launch duration from HIP events on the library's stream
+  "cpu_baseline"  the CPU oracle (a straight multithreaded port, oracle/) timed on this box's host
+                  cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def bytes_and_flops(st):
+    """Algorithmic bytes / flops of a set of path segments."""
+    rays = st["rays"]
+    b = (56 * st["n_inner"] + 40 * st["n_tri"] + 16 * st["n_sphere"] + 64 * rays
+         + 112 * st["hit_mesh"] + 16 * st["hit_textured"])
+    f = (22 * st["n_box"] + 48 * st["n_tri"] + 20 * st["n_sphere"] + 130 * (st["hit_mesh"] + st["hit_sphere"]))
+    return b, f
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="lamborghini")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--textures", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-spp", type=int, default=1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+
+    pt = importlib.import_module("path-tracer_amd")
+    L, H = pt.lib(), pt.host()
+    if not pt.gpu_available():
+        raise SystemExit("bench.py needs an MI355X: libptx_hip.so sees no HIP device (there is no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    H.pth_set_device(local_rank)
+    H.pth_set_seed(args.seed)
+    desc, cam = pt.load_scene(args.scene, width=args.width, height=args.height, textures=args.textures)
+    ctx = H.pth_context()
+    scene = H.pth_scene_device()
+    n_pix = cam.width * cam.height
+    n_tris = desc.contents.num_triangles
+
+    # accumulation buffer owned by torch so the collective can run on it in place
+    accum = torch.zeros((n_pix, 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+    pt.check(L.ptx_render_init(ctx, C.byref(cam), C.c_void_p(accum.data_ptr())), "ptx_render_init")
+
+    spp = args.spp_per_step
+    stats = pt.PtxStats()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        # global sample indices: step-major, rank-minor, disjoint across ranks and steps
+        first = (i * world + rank) * spp
+        pt.check(L.ptx_render_samples(ctx, scene, first, spp, args.seed, 0), "ptx_render_samples")
+
+    for i in range(args.warmup):
+        step(i)
+    pt.check(L.ptx_render_sync(ctx))
+    accum.zero_()
+    pt.check(L.ptx_stats_reset(ctx))
+    barrier()
+
+    kernel_ms = C.c_float(0)
+    t0 = time.perf_counter()
+    pt.check(L.ptx_timer_begin(ctx))
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    pt.check(L.ptx_timer_end(ctx, C.byref(kernel_ms)))     # also waits for the launches
+    if world > 1:
+        dist.all_reduce(accum, op=dist.ReduceOp.SUM)      # the one exchange step of the job
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    pt.check(L.ptx_stats_get(ctx, C.byref(stats)))
+    rays_local = torch.tensor([float(stats.rays), elapsed, float(kernel_ms.value)], dtype=torch.float64,
+                              device=f"cuda:{local_rank}")
+    if world > 1:
+        rays_sum = rays_local.clone()
+        dist.all_reduce(rays_sum, op=dist.ReduceOp.SUM)
+        tmax = rays_local.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        total_rays, max_elapsed, max_kernel_ms = rays_sum[0].item(), tmax[1].item(), tmax[2].item()
+    else:
+        total_rays, max_elapsed, max_kernel_ms = float(stats.rays), elapsed, float(kernel_ms.value)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline leg (rank 0): counters of the SAME samples from the counting variant --------------
+    pt.check(L.ptx_stats_reset(ctx))
+    pt.check(L.ptx_render_samples(ctx, scene, (args.warmup * world + rank) * spp, spp, args.seed, 1))
+    pt.check(L.ptx_render_sync(ctx))
+    cst = pt.PtxStats()
+    pt.check(L.ptx_stats_get(ctx, C.byref(cst)))
+    cd = cst.as_dict()
+    b_launch, f_launch = bytes_and_flops(cd)
+    launch_ms = float(kernel_ms.value) / args.steps
+    achieved_gbs = b_launch / (launch_ms * 1e-3) / 1e9
+    achieved_tflops = f_launch / (launch_ms * 1e-3) / 1e12
+    lane_frac = cd["lane_steps_active"] / max(1, cd["lane_steps_total"])
+    roofline = {
+        "kernel": "render_kernel<0>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+        "launch_ms": round(launch_ms, 3), "bytes_per_launch": b_launch, "rays_per_launch": cd["rays"],
+        "bytes_per_ray": round(b_launch / max(1, cd["rays"]), 1),
+        "valu": {"achieved": round(achieved_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(achieved_tflops / VALU_PEAK_TFLOPS, 5), "flops_per_ray": round(f_launch / max(1, cd["rays"]), 1),
+                 "active_lane_frac_segments": round(lane_frac, 4)},
+        "per_ray": {k: round(cd[k] / max(1, cd["rays"]), 3) for k in ("n_inner", "n_box", "n_tri", "n_sphere", "n_leaf")},
+    }
+
+    # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------
+    cpu = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import numpy as np
+        import orc
+        threads = min(16, os.cpu_count() or 1)
+        acc = np.zeros((n_pix, 4), np.float32)
+        ost = pt.PtxStats()
+        tc = time.perf_counter()
+        rc = orc.lib().orc_render(desc, C.byref(cam), 0, args.cpu_spp, args.seed, orc.fptr(acc), threads, C.byref(ost))
+        dt = time.perf_counter() - tc
+        assert rc == 0
+        cpu = {"value": round(ost.rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+               "sample": f"{args.cpu_spp} spp of the full {cam.width}x{cam.height} frame ({int(ost.rays)} rays, {dt:.1f} s)"}
+
+    out = {
+        "metric": "Mrays/s (whole node), Lamborghini 1920x1080", "value": round(total_rays / max_elapsed / 1e6, 2),
+        "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(max_elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"scenes/scene_{args.scene}.json at {cam.width}x{cam.height}, textures "
+                               f"{'on' if args.textures else 'off'}, 5 bounces; lp560.obj absent -> procedural stand-in car",
+                   "triangles": n_tris, "spp_per_step_per_gpu": spp, "samples_per_s": round(n_pix * spp * args.steps * world / max_elapsed, 1),
+                   "time_to_1k_spp_s": round(1000.0 / (spp * args.steps * world / max_elapsed), 2),
+                   "parallelism": f"spp-split x{world}"},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

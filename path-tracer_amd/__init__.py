@@ -106,7 +106,7 @@ _oracle = None
 def _load(path, what):
     if not os.path.exists(path):
         raise RuntimeError(f"{what} is not built: {path} missing (run __graft_entry__.build() or `make -C path-tracer_amd`)")
-    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return C.CDLL(path)  # RTLD_LOCAL: the reference-built pin library defines the same C++ names
 
 
 def lib():

@@ -30,15 +30,17 @@ static DialogLogger* reporter = NULL;
 WorldObjectsSources world_obj_sources;
 
 // host resources of the loaded scene (reference: dv_mem_ptrs / dv_textures / dv_mem_kdtrees_ptrs, :36-38)
-static std::vector<void*> host_mem_ptrs;
-static std::vector<KDNode*> host_kdtrees;
-static std::vector<HostTexture> host_textures;
-static std::map<std::string, int> texture_by_path;
-static std::vector<WorldObject> host_wobjects;
-static HostSceneFlat flat_scene;
+// heap-allocated and never destroyed: the global sceneState's destructor (another translation unit)
+// calls freeWorldObjects() during static destruction and must still find these alive
+static std::vector<void*>& host_mem_ptrs = *new std::vector<void*>();
+static std::vector<KDNode*>& host_kdtrees = *new std::vector<KDNode*>();
+static std::vector<HostTexture>& host_textures = *new std::vector<HostTexture>();
+static std::map<std::string, int>& texture_by_path = *new std::map<std::string, int>();
+static std::vector<WorldObject>& host_wobjects = *new std::vector<WorldObject>();
+static HostSceneFlat& flat_scene = *new HostSceneFlat();
 static PtxScene* device_scene = NULL;
 
-static std::string asset_root;
+static std::string& asset_root = *new std::string();
 static int procedural_car_triangles = 400000;
 static bool device_upload_enabled = true;
 
