@@ -39,7 +39,8 @@ struct DevObject {
 	float bmin[3];          // root box (mesh)
 	int32_t first_node;     // scene-global index of node 0 (to report local leaf ids)
 	float bmax[3];
-	int32_t pad;
+	int32_t big_slot;       // >= 0: mesh with inner nodes, traversed by the wavefront's traversal kernel
+	                        //       through queue `big_slot`; -1: sphere / single-leaf mesh (tested inline)
 };
 
 struct DevTexture {

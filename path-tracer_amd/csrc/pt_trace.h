@@ -84,7 +84,7 @@ PT_DEV bool tri_test(const Ray& r, f3 va, f3 e1, f3 e2, float& res_t, float& ru,
 }
 
 // reference: src/intersect.cuh:59-83 testSphereIntersection
-PT_DEV bool sphere_test(const Ray& r, float rad, f3 center, f3& hit_point, f3& hit_norm) {
+PT_DEV bool sphere_test(const Ray& r, float rad, f3 center, f3& hit_point, f3& hit_norm, float& t_out) {
 	f3 op = center - r.o;
 	const float epsilon = 0.0001f;
 	float b = dot3(op, r.d);
@@ -96,46 +96,98 @@ PT_DEV bool sphere_test(const Ray& r, float rad, f3 center, f3& hit_point, f3& h
 	if (t < epsilon) return false;
 	hit_point = r.o + r.d * t;
 	hit_norm = normalize3(hit_point - center);
+	t_out = t;
 	return true;
 }
 
-// reference: src/intersect.cuh:119-212 rayIntersectsKDNodeLOOP.
+// reference: src/intersect.cuh:119-212 rayIntersectsKDNodeLOOP, after the root box test.
 // stack: this lane's column in LDS, element i at stack[i * stride].
 // Returns "some triangle test succeeded"; best_tri (index into tri_geom/tri_shade), bu, bv and
 // tmin are updated only when a strictly closer hit is found (strict <, first wins ties).
+//
+// Loop shape ("while-while"): a lane first DESCENDS through inner nodes until it holds a leaf, then
+// tests that leaf's triangles, then pops. The lanes of a wave therefore run the two kinds of work in
+// two separate inner loops instead of serialising a leaf body and an inner-node body every
+// iteration. A node record is fetched whole (4 x 16 B, one 64-B line) before the leaf/inner decision
+// so the decision does not add a dependent round trip; the next triangle is fetched while the
+// current one is tested.
 template <int FLAGS>
-PT_DEV bool traverse_mesh(const DevScene& sc, const DevObject& ob, int obj_index, const Ray& ray,
-                          int* stack, int stride, float& tmin, int& best_tri, float& bu, float& bv,
-                          TraceCounters& cnt, float& dbg) {
-	if (ob.root_node < 0) return false;
-	float dist;
-	if (FLAGS & PT_F_STATS) cnt.n_box++;
-	if (!box_test(ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], ray, dist))
-		return false;
-	if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
-
+PT_DEV bool traverse_nodes(const DevScene& sc, const DevObject& ob, int obj_index, const Ray& ray,
+                           int* stack, int stride, float& tmin, int& best_tri, float& bu, float& bv,
+                           TraceCounters& cnt, float& dbg, uint32_t& steps) {
 	bool intersects = false;
 	int sp = 0;          // number of entries on the stack
 	int curr = ob.root_node;
 	const float4* __restrict__ nodes = sc.nodes;
 	const float4* __restrict__ geom = sc.tri_geom;
 
-	while (curr >= 0) {
-		const float4 q3 = nodes[4 * curr + 3];
-		const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-		if (left == -1 && right == -1) {
-			// leaf: test all triangles of the node, in list order
-			const int first = __float_as_int(q3.z), count = __float_as_int(q3.w);
-			if (FLAGS & PT_F_STATS) {
-				cnt.n_leaf++;
-				cnt.n_tri += (uint32_t)count;
-				fnv_word(cnt.leaf_hash, (uint32_t)obj_index);
-				fnv_word(cnt.leaf_hash, (uint32_t)(curr - ob.first_node));
+	for (;;) {
+		int first = 0, count = -1;
+		// ---- descend until a leaf is reached or the traversal is over -----------------------
+		while (curr >= 0) {
+			const float4 q3 = nodes[4 * curr + 3];
+			const float4 q0 = nodes[4 * curr + 0];
+			const float4 q1 = nodes[4 * curr + 1];
+			const float4 q2 = nodes[4 * curr + 2];
+			if (FLAGS & PT_F_STATS) steps++;
+			const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+			if (left == -1 && right == -1) {
+				first = __float_as_int(q3.z);
+				count = __float_as_int(q3.w);
+				if (FLAGS & PT_F_STATS) {
+					cnt.n_leaf++;
+					cnt.n_tri += (uint32_t)count;
+					fnv_word(cnt.leaf_hash, (uint32_t)obj_index);
+					fnv_word(cnt.leaf_hash, (uint32_t)(curr - ob.first_node));
+				}
+				break;
 			}
+			// inner node: test both child boxes (stored in this record)
+			if (FLAGS & PT_F_STATS) cnt.n_inner++;
+			float left_dist = __builtin_huge_valf(), right_dist = __builtin_huge_valf();
+			bool left_res = false, right_res = false;
+			if (left != -1) {
+				if (FLAGS & PT_F_STATS) cnt.n_box++;
+				left_res = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ray, left_dist) && (left_dist < tmin);
+			}
+			if (right != -1) {
+				if (FLAGS & PT_F_STATS) cnt.n_box++;
+				right_res = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ray, right_dist) && (right_dist < tmin);
+			}
+			if (left_res && right_res) {
+				// nearer child first; tie -> left first (reference :183-187)
+				int further = right;
+				int next = right;
+				if (left_dist > right_dist) further = left; else next = left;
+				stack[sp * stride] = further;
+				++sp;
+				curr = next;
+				if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.9025f;
+			} else if (left_res) {
+				curr = left;
+				if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
+			} else if (right_res) {
+				curr = right;
+				if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
+			} else {
+				if (sp == 0) { curr = -1; break; }
+				--sp;
+				curr = stack[sp * stride];
+			}
+		}
+		if (count < 0) break; // no leaf: traversal finished
+
+		// ---- leaf: test all triangles of the node, in list order -----------------------------
+		if (count > 0) {
+			float4 g0 = geom[3 * first + 0], g1 = geom[3 * first + 1], g2 = geom[3 * first + 2];
 			for (int i = 0; i < count; ++i) {
-				const float4 g0 = geom[3 * (first + i) + 0];
-				const float4 g1 = geom[3 * (first + i) + 1];
-				const float4 g2 = geom[3 * (first + i) + 2];
+				float4 n0 = g0, n1 = g1, n2 = g2;
+				if (i + 1 < count) {
+					n0 = geom[3 * (first + i + 1) + 0];
+					n1 = geom[3 * (first + i + 1) + 1];
+					n2 = geom[3 * (first + i + 1) + 2];
+				}
+				if (FLAGS & PT_F_STATS) steps++;
 				float t, u, v;
 				if (tri_test(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
 					intersects = true;
@@ -146,51 +198,30 @@ PT_DEV bool traverse_mesh(const DevScene& sc, const DevObject& ob, int obj_index
 						bv = v;
 					}
 				}
+				g0 = n0; g1 = n1; g2 = n2;
 			}
-			// pop
-			if (sp == 0) break;
-			--sp;
-			curr = stack[sp * stride];
-			continue;
 		}
-
-		// inner node: test both child boxes (stored in this record)
-		const float4 q0 = nodes[4 * curr + 0];
-		const float4 q1 = nodes[4 * curr + 1];
-		const float4 q2 = nodes[4 * curr + 2];
-		if (FLAGS & PT_F_STATS) cnt.n_inner++;
-		float left_dist = __builtin_huge_valf(), right_dist = __builtin_huge_valf();
-		bool left_res = false, right_res = false;
-		if (left != -1) {
-			if (FLAGS & PT_F_STATS) cnt.n_box++;
-			left_res = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ray, left_dist) && (left_dist < tmin);
-		}
-		if (right != -1) {
-			if (FLAGS & PT_F_STATS) cnt.n_box++;
-			right_res = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ray, right_dist) && (right_dist < tmin);
-		}
-		if (left_res && right_res) {
-			// nearer child first; tie -> left first (reference :183-187)
-			int further = right;
-			int next = right;
-			if (left_dist > right_dist) further = left; else next = left;
-			stack[sp * stride] = further;
-			++sp;
-			curr = next;
-			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.9025f;
-		} else if (left_res) {
-			curr = left;
-			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
-		} else if (right_res) {
-			curr = right;
-			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
-		} else {
-			if (sp == 0) break;
-			--sp;
-			curr = stack[sp * stride];
-		}
+		// pop
+		if (sp == 0) break;
+		--sp;
+		curr = stack[sp * stride];
 	}
 	return intersects;
+}
+
+// root box test (reference :130-135) + traversal
+template <int FLAGS>
+PT_DEV bool traverse_mesh(const DevScene& sc, const DevObject& ob, int obj_index, const Ray& ray,
+                          int* stack, int stride, float& tmin, int& best_tri, float& bu, float& bv,
+                          TraceCounters& cnt, float& dbg) {
+	if (ob.root_node < 0) return false;
+	float dist;
+	if (FLAGS & PT_F_STATS) cnt.n_box++;
+	if (!box_test(ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], ray, dist))
+		return false;
+	if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
+	uint32_t steps = 0;
+	return traverse_nodes<FLAGS>(sc, ob, obj_index, ray, stack, stride, tmin, best_tri, bu, bv, cnt, dbg, steps);
 }
 
 struct HitInfo {
@@ -222,11 +253,14 @@ PT_DEV bool intersect_scene(const DevScene& sc, const Ray& ray, int* stack, int 
 		bool hit;
 		if (ob.type == 0) {
 			if (FLAGS & PT_F_STATS) cnt.n_sphere++;
-			hit = sphere_test(ray, ob.radius, mk3(ob.px, ob.py, ob.pz), p, nrm);
+			float ts;
+			hit = sphere_test(ray, ob.radius, mk3(ob.px, ob.py, ob.pz), p, nrm, ts);
 		} else {
 			float tmin = __builtin_huge_valf();
 			float bu = 0.0f, bv = 0.0f;
 			hit = traverse_mesh<FLAGS>(sc, ob, i, ray, stack, stride, tmin, tri, bu, bv, cnt, dbg);
+			// a "hit" at t = +inf never beats tmin; the reference would dereference a NULL triangle there
+			hit = hit && tri >= 0;
 			if (hit) {
 				// reference :300-305
 				p = ray.o + tmin * ray.d;

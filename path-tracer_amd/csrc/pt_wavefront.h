@@ -1,0 +1,326 @@
+// Wavefront path tracer: the hot path as a per-bounce pipeline over ALL paths of a sample batch.
+//
+// Why: in a one-lane-per-pixel megakernel the wave waits for its slowest lane. In the headline
+// scene only ~1 ray in 3 enters the car's KD-tree, and those rays do hundreds of triangle tests
+// while their 40-odd neighbours idle (measured: 8 % useful lanes, 68 % of wave time waiting,
+// profiles/r01_baseline_*). Here rays that need the expensive traversal are compacted into a
+// queue (ballot + popcount prefix inside the wave, ONE atomic per wave) and a dedicated kernel
+// traverses them with full waves and few registers (high occupancy to hide L2/MALL latency).
+//
+// Pipeline for a batch of B samples (paths = B x padded pixel count, path id = sample-major,
+// then 8x8 pixel tiles, so a wave starts on one tile of one sample):
+//   for bounce = 0 .. max_bounces:
+//     wf_segment_kernel   bounce 0: jittered primary ray (generatePrimaryRays + jitterPrimaryRays)
+//                         bounce>0: resolve the previous segment's closest hit, shade / sample the
+//                                   BSDF (gatherRadiance body), terminate on miss / light / last bounce
+//                         then intersect the new ray with all CHEAP objects inline (spheres, single-leaf
+//                         meshes), root-box-test the multi-node meshes and enqueue the ray for those it
+//                         enters; survivors are appended to the next live list (stream compaction)
+//     wf_traverse_kernel  one launch per multi-node mesh: short-stack KD traversal (stack in LDS) of the
+//                         queued rays, merged into the path's closest-hit record
+//   wf_accumulate_kernel  acc[pixel] += radiance[sample][pixel] in SAMPLE ORDER
+//
+// Determinism: a path's arithmetic does not depend on which lane runs it or in what order queues are
+// filled; terminated paths park their radiance in rad[sample][pixel] and the accumulation adds them
+// in sample order, so the result is bit-identical to one-sample-per-launch (the reference schedule).
+// Closest hit across objects = smallest length(ipoint - origin), ties to the lower object index —
+// exactly what the reference's in-order loop with strict '<' yields (src/intersect.cuh:328-346).
+//
+// Path state in HBM, 4 x float4 per path (64 B), SoA so lanes of a wave read consecutive 16-B words:
+//   s0 = (origin.xyz, best_dist)   s1 = (dir.xyz, best_t)
+//   s2 = (mask.rgb, int best_obj)  s3 = (int best_tri, bary_u, bary_v, -)
+#pragma once
+#include "pt_kernels.h"
+
+#define PT_MAX_BIG 32   // = PTX_MAX_OBJECTS: every mesh may be a multi-node one
+#define PT_WF_MAX_BOUNCES 64
+
+struct WfParams {
+	float4* s0; float4* s1; float4* s2; float4* s3;
+	float4* rad;              // [batch][npix]
+	int* live[2];             // ping-pong live-path lists
+	int* queue[PT_MAX_BIG];   // per multi-node mesh: path ids whose ray enters its root box
+	int* counters;            // [bounce][1 + PT_MAX_BIG]: live count, queue counts (zeroed per batch)
+	PtxStats* stats;
+	int first_sample, batch;
+	int npt;                  // padded pixels per sample = tiles * 64
+	int tiles_x, npix, n_total;
+	uint32_t k0, k1;
+	int bounce, is_last;
+};
+
+#define WF_CNT(wp, b, k) ((wp).counters[(b) * (1 + PT_MAX_BIG) + (k)])
+
+// Stream compaction inside a wave: returns the slot of this lane in the list `counter` counts, or -1.
+// Must be reached by whole waves (callers keep their loops wave-uniform).
+PT_DEV int wave_append(int* counter, bool pred) {
+	const unsigned long long m = __ballot(pred);
+	if (m == 0ull) return -1;
+	const int lane = threadIdx.x & 63;
+	const int leader = (int)__ffsll((long long)m) - 1;
+	int base = 0;
+	if (lane == leader) base = atomicAdd(counter, (int)__popcll(m));
+	base = __shfl(base, leader, 64);
+	const int rank = (int)__popcll(m & ((1ull << lane) - 1ull));
+	return pred ? base + rank : -1;
+}
+
+PT_DEV void stats_flush(PtxStats* stats, const TraceCounters& cnt, uint64_t rays, uint64_t paths, uint64_t hm, uint64_t hs,
+                        uint64_t ht, uint64_t act, uint64_t tot, bool detailed) {
+	const int lane = threadIdx.x & 63;
+	rays = wave_sum_u64(rays);
+	paths = wave_sum_u64(paths);
+	uint64_t c_inner = 0, c_box = 0, c_tri = 0, c_sphere = 0, c_leaf = 0;
+	if (detailed) {
+		c_inner = wave_sum_u64(cnt.n_inner); c_box = wave_sum_u64(cnt.n_box); c_tri = wave_sum_u64(cnt.n_tri);
+		c_sphere = wave_sum_u64(cnt.n_sphere); c_leaf = wave_sum_u64(cnt.n_leaf);
+		hm = wave_sum_u64(hm); hs = wave_sum_u64(hs); ht = wave_sum_u64(ht);
+		act = wave_sum_u64(act); tot = wave_sum_u64(tot);
+	}
+	if (lane == 0) {
+		if (rays) atomicAdd((unsigned long long*)&stats->rays, (unsigned long long)rays);
+		if (paths) atomicAdd((unsigned long long*)&stats->paths, (unsigned long long)paths);
+		if (detailed) {
+			atomicAdd((unsigned long long*)&stats->n_inner, (unsigned long long)c_inner);
+			atomicAdd((unsigned long long*)&stats->n_box, (unsigned long long)c_box);
+			atomicAdd((unsigned long long*)&stats->n_tri, (unsigned long long)c_tri);
+			atomicAdd((unsigned long long*)&stats->n_sphere, (unsigned long long)c_sphere);
+			atomicAdd((unsigned long long*)&stats->n_leaf, (unsigned long long)c_leaf);
+			atomicAdd((unsigned long long*)&stats->hit_mesh, (unsigned long long)hm);
+			atomicAdd((unsigned long long*)&stats->hit_sphere, (unsigned long long)hs);
+			atomicAdd((unsigned long long*)&stats->hit_textured, (unsigned long long)ht);
+			atomicAdd((unsigned long long*)&stats->lane_steps_active, (unsigned long long)act);
+			atomicAdd((unsigned long long*)&stats->lane_steps_total, (unsigned long long)tot);
+		}
+	}
+}
+
+// A single-leaf mesh (root is a leaf): all lanes walk the same triangle run, whose addresses are
+// wave-uniform, so the compiler can fetch the triangles with scalar loads.
+template <int FLAGS>
+PT_DEV bool leaf_only_mesh(const DevScene& sc, const DevObject& ob, const Ray& ray, float& tmin, int& best_tri,
+                           float& bu, float& bv, TraceCounters& cnt) {
+	const float4 q3 = sc.nodes[4 * ob.root_node + 3];
+	const int first = __builtin_amdgcn_readfirstlane(__float_as_int(q3.z));
+	const int count = __builtin_amdgcn_readfirstlane(__float_as_int(q3.w));
+	if (FLAGS & PT_F_STATS) { cnt.n_leaf++; cnt.n_tri += (uint32_t)count; }
+	bool intersects = false;
+	for (int i = 0; i < count; ++i) {
+		const float4 g0 = sc.tri_geom[3 * (first + i) + 0];
+		const float4 g1 = sc.tri_geom[3 * (first + i) + 1];
+		const float4 g2 = sc.tri_geom[3 * (first + i) + 2];
+		float t, u, v;
+		if (tri_test(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
+			intersects = true;
+			if (t < tmin) { tmin = t; best_tri = first + i; bu = u; bv = v; }
+		}
+	}
+	return intersects;
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCamera cam, WfParams wp) {
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int bounce = wp.bounce;
+	const int n_in = bounce == 0 ? wp.n_total : WF_CNT(wp, bounce - 1, 0);
+	const int* __restrict__ live_in = wp.live[(bounce & 1) ^ 1];
+	int* __restrict__ live_out = wp.live[bounce & 1];
+	const f3 cam_pos = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+
+	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
+	uint64_t n_rays = 0, n_paths = 0, c_hm = 0, c_hs = 0, c_ht = 0;
+
+	for (int i0 = (int)blockIdx.x * PT_BLOCK + (tid & ~63); i0 < n_in; i0 += (int)gridDim.x * PT_BLOCK) {
+		const int i = i0 + lane;
+		bool alive = i < n_in;
+		int path = 0;
+		if (alive) path = bounce == 0 ? i : live_in[i];
+		// path id -> (sample, pixel): sample-major, then 8x8 tiles, lane = x + 8 y inside the tile
+		const int sl = path / wp.npt, r = path - sl * wp.npt;
+		const int tile = r >> 6, l = r & 63;
+		const int x = (tile % wp.tiles_x) * 8 + (l & 7);
+		const int y = (tile / wp.tiles_x) * 8 + (l >> 3);
+		if (x >= cam.width || y >= cam.height) alive = false;
+		const uint32_t pixel = (uint32_t)(x + y * cam.width);
+		const uint32_t sample = (uint32_t)(wp.first_sample + sl);
+		float4* rad_slot = wp.rad + (size_t)sl * (size_t)wp.npix + pixel;
+
+		Ray ray;
+		f3 mask = mk3(1.0f);
+		if (alive) {
+			if (bounce == 0) {
+				f3 mid, centre;
+				pixel_midpoint(cam, x, y, mid, centre);
+				init_ray(ray, cam_pos, jittered_dir(cam, mid, pixel, sample, wp.k0, wp.k1));
+				if (wp.is_last) { // max_ray_bounces == 0: the bounce loop never runs
+					*rad_slot = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					n_paths++;
+					alive = false;
+				}
+			} else {
+				// ---- resolve the closest hit of the previous segment and shade it ------------------
+				const float4 a0 = wp.s0[path], a1 = wp.s1[path], a2 = wp.s2[path], a3 = wp.s3[path];
+				init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
+				mask = mk3(a2.x, a2.y, a2.z);
+				const int best_obj = __float_as_int(a2.w);
+				f3 out = mk3(0.0f);
+				bool done;
+				if (best_obj < 0) {
+					done = true; // miss: reference src/radiance.cuh:30-34
+				} else {
+					const DevObject& ob = sc.objects[best_obj];
+					HitInfo hi;
+					hi.object = best_obj;
+					hi.dist = a0.w;
+					hi.point = ray.o + ray.d * a1.w;
+					if (ob.type == 0) {
+						hi.tri = -1;
+						hi.bary = mk3(0.0f);
+						hi.material = ob.mat_first;
+						hi.normal = normalize3(hi.point - mk3(ob.px, ob.py, ob.pz));
+						if (FLAGS & PT_F_STATS) c_hs++;
+					} else {
+						hi.tri = __float_as_int(a3.x);
+						hi.bary.y = a3.y;
+						hi.bary.z = a3.z;
+						hi.bary.x = 1.0f - hi.bary.y - hi.bary.z;
+						const float4 t0 = sc.tri_shade[4 * hi.tri + 0];
+						const float4 t1 = sc.tri_shade[4 * hi.tri + 1];
+						const float4 t2 = sc.tri_shade[4 * hi.tri + 2];
+						const float4 t3 = sc.tri_shade[4 * hi.tri + 3];
+						hi.normal = normalize3(hi.bary.x * mk3(t0.x, t0.y, t0.z) + hi.bary.y * mk3(t1.x, t1.y, t1.z) +
+						                       hi.bary.z * mk3(t2.x, t2.y, t2.z));
+						hi.material = __float_as_int(t3.w);
+						if (FLAGS & PT_F_STATS) c_hm++;
+					}
+					if (FLAGS & PT_F_STATS) {
+						const MaterialRec mt = load_material(sc, hi.material);
+						if (cam.texture_enabled && mt.texture > -1 && hi.tri >= 0) c_ht++;
+					}
+					const u4 rnd = philox4x32_10(pixel, sample, (uint32_t)(bounce - 1), 0u, wp.k0, wp.k1);
+					done = shade_segment(sc, cam, hi, ray, mask, rnd, out);
+					if (!done && wp.is_last) { done = true; out = mk3(0.0f); } // bounce loop exhausted (:86)
+				}
+				if (done) {
+					*rad_slot = make_float4(out.x, out.y, out.z, 0.0f);
+					n_paths++;
+					alive = false;
+				}
+			}
+		}
+
+		// ---- intersect the new segment with the cheap objects, enqueue it for the expensive ones ----
+		float best_dist = __builtin_huge_valf(), best_t = 0.0f, b_u = 0.0f, b_v = 0.0f;
+		int best_obj = -1, best_tri = -1;
+		if (alive) n_rays++;
+		const int nobj = sc.num_objects;
+		for (int oi = 0; oi < nobj; ++oi) {
+			const DevObject& ob = sc.objects[oi];
+			if (ob.type == 0) {
+				if (alive) {
+					if (FLAGS & PT_F_STATS) cnt.n_sphere++;
+					f3 p, nrm;
+					float t;
+					if (sphere_test(ray, ob.radius, mk3(ob.px, ob.py, ob.pz), p, nrm, t)) {
+						const float d = length3(p - ray.o);
+						if (d < best_dist) { best_dist = d; best_t = t; best_obj = oi; best_tri = -1; }
+					}
+				}
+			} else if (ob.root_node >= 0) {
+				bool enter = false;
+				if (alive) {
+					float rd;
+					if (FLAGS & PT_F_STATS) cnt.n_box++;
+					enter = box_test(ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], ray, rd);
+				}
+				if (ob.big_slot >= 0) {
+					const int slot = wave_append(&WF_CNT(wp, bounce, 1 + ob.big_slot), enter);
+					if (slot >= 0) wp.queue[ob.big_slot][slot] = path;
+				} else if (enter) {
+					float tmin = __builtin_huge_valf(), bu = 0.0f, bv = 0.0f;
+					int tri = -1;
+					bool hit = leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
+					if (hit && tri >= 0) {
+						const f3 p = ray.o + tmin * ray.d;
+						const float d = length3(p - ray.o);
+						if (d < best_dist) { best_dist = d; best_t = tmin; best_obj = oi; best_tri = tri; b_u = bu; b_v = bv; }
+					}
+				}
+			}
+		}
+		if (alive) {
+			wp.s0[path] = make_float4(ray.o.x, ray.o.y, ray.o.z, best_dist);
+			wp.s1[path] = make_float4(ray.d.x, ray.d.y, ray.d.z, best_t);
+			wp.s2[path] = make_float4(mask.x, mask.y, mask.z, __int_as_float(best_obj));
+			wp.s3[path] = make_float4(__int_as_float(best_tri), b_u, b_v, 0.0f);
+		}
+		const int slot = wave_append(&WF_CNT(wp, bounce, 0), alive);
+		if (slot >= 0) live_out[slot] = path;
+	}
+	stats_flush(wp.stats, cnt, n_rays, n_paths, c_hm, c_hs, c_ht, 0, 0, (FLAGS & PT_F_STATS) != 0);
+}
+
+// KD traversal of the rays queued for one multi-node mesh; merges into the path's closest-hit record.
+template <int FLAGS>
+__global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
+	extern __shared__ int lds_stack[];
+	const int tid = threadIdx.x, lane = tid & 63;
+	int* stack = lds_stack + tid;
+	const DevObject& ob = sc.objects[obj_index];
+	const int n = WF_CNT(wp, wp.bounce, 1 + slot_index);
+	const int* __restrict__ queue = wp.queue[slot_index];
+	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
+	uint64_t act = 0, tot = 0;
+
+	for (int i0 = (int)blockIdx.x * PT_BLOCK + (tid & ~63); i0 < n; i0 += (int)gridDim.x * PT_BLOCK) {
+		const int i = i0 + lane;
+		uint32_t steps = 0;
+		if (i < n) {
+			const int path = queue[i];
+			const float4 a0 = wp.s0[path], a1 = wp.s1[path];
+			Ray ray;
+			init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
+			float tmin = __builtin_huge_valf(), bu = 0.0f, bv = 0.0f, dbg = 1.0f;
+			int tri = -1;
+			const bool hit = traverse_nodes<FLAGS>(sc, ob, obj_index, ray, stack, PT_BLOCK, tmin, tri, bu, bv, cnt, dbg, steps);
+			if (hit && tri >= 0) {
+				const f3 p = ray.o + tmin * ray.d;
+				const float d = length3(p - ray.o);
+				const int cur_obj = __float_as_int(wp.s2[path].w);
+				const float cur_d = a0.w;
+				// strict '<' in object order == smaller distance, ties to the lower object index
+				if (d < cur_d || (d == cur_d && cur_obj >= 0 && obj_index < cur_obj)) {
+					wp.s0[path].w = d;
+					wp.s1[path].w = tmin;
+					wp.s2[path].w = __int_as_float(obj_index);
+					wp.s3[path] = make_float4(__int_as_float(tri), bu, bv, 0.0f);
+				}
+			}
+		}
+		if (FLAGS & PT_F_STATS) {
+			// lane utilisation of the traversal: own steps vs 64 x the slowest lane of this round
+			uint32_t mx = steps;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) {
+				const uint32_t v = (uint32_t)__shfl_xor((int)mx, o, 64);
+				mx = v > mx ? v : mx;
+			}
+			act += steps;
+			if (lane == 0) tot += 64ull * mx;
+		}
+	}
+	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0);
+}
+
+// reference: src/pathtracing.cu:151 acc_image[index] += make_float4(radiance), once per iteration, in order
+__global__ __launch_bounds__(PT_BLOCK) void wf_accumulate_kernel(float4* __restrict__ accum, const float4* __restrict__ rad,
+                                                                 int npix, int batch) {
+	const int p = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (p >= npix) return;
+	float4 acc = accum[p];
+	for (int s = 0; s < batch; ++s) {
+		const float4 r = rad[(size_t)s * (size_t)npix + p];
+		acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += 0.0f;
+	}
+	accum[p] = acc;
+}

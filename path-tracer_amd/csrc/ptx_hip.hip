@@ -2,7 +2,8 @@
 // Host side of the library: argument validation, the packed scene upload, launches.
 // There is no CPU fallback anywhere in this file: without a HIP device every compute
 // entry point returns an error.
-#include "pt_kernels.h"
+#include "pt_wavefront.h"
+#include <cstdlib>
 
 #include <cstdarg>
 #include <cstdio>
@@ -41,6 +42,12 @@ struct PtxCtx {
 	size_t pbo_pixels;
 	hipEvent_t ev0, ev1;
 	bool timer_open;
+	// wavefront pipeline buffers (allocated on first use, grown on demand)
+	WfParams wf;
+	size_t wf_paths, wf_rad;   // capacities (paths, rad entries)
+	int wf_queues;
+	int wf_batch;              // samples per wavefront pass
+	bool force_megakernel;
 };
 
 struct PtxScene {
@@ -51,6 +58,8 @@ struct PtxScene {
 	int num_objects;
 	int max_depth;
 	int num_dev_triangles;
+	int num_big;                       // meshes with inner nodes
+	int big_object[PT_MAX_BIG];        // their object indices, by queue slot
 };
 
 extern "C" const char* ptx_last_error(void) { return g_last_error.c_str(); }
@@ -96,17 +105,58 @@ extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 	hipMemsetAsync(c->d_stats, 0, sizeof(PtxStats), c->stream);
 	hipEventCreate(&c->ev0);
 	hipEventCreate(&c->ev1);
+	const char* eb = getenv("PTX_WF_BATCH");
+	c->wf_batch = eb ? atoi(eb) : 8;
+	if (c->wf_batch < 1) c->wf_batch = 1;
+	if (c->wf_batch > 64) c->wf_batch = 64;
+	const char* em = getenv("PTX_MEGAKERNEL");
+	c->force_megakernel = em && atoi(em) != 0;
 	*out = c;
 	return PTX_OK;
 }
 
 extern "C" int ptx_render_cleanup(PtxCtx* ctx);
 
+static void wf_free(PtxCtx* c) {
+	void* ptrs[] = {c->wf.s0, c->wf.s1, c->wf.s2, c->wf.s3, c->wf.rad, c->wf.live[0], c->wf.live[1], c->wf.counters};
+	for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i)
+		if (ptrs[i]) hipFree(ptrs[i]);
+	for (int k = 0; k < PT_MAX_BIG; ++k)
+		if (c->wf.queue[k]) hipFree(c->wf.queue[k]);
+	memset(&c->wf, 0, sizeof(c->wf));
+	c->wf_paths = c->wf_rad = 0;
+	c->wf_queues = 0;
+}
+
+// Path-state, live-list, queue and radiance buffers for `paths` paths / `rad` radiance slots / `queues` queues.
+static int wf_ensure(PtxCtx* c, size_t paths, size_t rad, int queues) {
+	if (paths <= c->wf_paths && rad <= c->wf_rad && queues <= c->wf_queues) return PTX_OK;
+	HIP_TRY(hipStreamSynchronize(c->stream));
+	if (paths < c->wf_paths) paths = c->wf_paths;
+	if (rad < c->wf_rad) rad = c->wf_rad;
+	if (queues < c->wf_queues) queues = c->wf_queues;
+	wf_free(c);
+	HIP_TRY(hipMalloc((void**)&c->wf.s0, paths * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.s1, paths * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.s2, paths * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.s3, paths * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.rad, rad * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.live[0], paths * sizeof(int)));
+	HIP_TRY(hipMalloc((void**)&c->wf.live[1], paths * sizeof(int)));
+	for (int k = 0; k < queues; ++k) HIP_TRY(hipMalloc((void**)&c->wf.queue[k], paths * sizeof(int)));
+	HIP_TRY(hipMalloc((void**)&c->wf.counters, (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) * sizeof(int)));
+	c->wf_paths = paths;
+	c->wf_rad = rad;
+	c->wf_queues = queues;
+	return PTX_OK;
+}
+
 extern "C" int ptx_ctx_destroy(PtxCtx* ctx) {
 	if (!ctx) return PTX_OK;
 	hipSetDevice(ctx->device);
 	hipStreamSynchronize(ctx->stream);
 	ptx_render_cleanup(ctx);
+	wf_free(ctx);
 	if (ctx->d_stats) hipFree(ctx->d_stats);
 	if (ctx->d_pbo) hipFree(ctx->d_pbo);
 	hipEventDestroy(ctx->ev0);
@@ -165,6 +215,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	geom.reserve((size_t)d->num_leaf_tris * 3);
 	shade.reserve((size_t)d->num_leaf_tris * 4);
 	int scene_max_depth = 0;
+	int num_big = 0, big_object[PT_MAX_BIG];
 
 	for (int m = 0; m < d->num_materials; ++m) {
 		const PtxMaterial& pm = d->materials[m];
@@ -183,6 +234,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 		dv.type = o.type;
 		dv.mat_first = o.first_material;
 		dv.root_node = -1;
+		dv.big_slot = -1;
 		if (o.type == PTX_OBJ_SPHERE) {
 			dv.radius = o.radius;
 			dv.px = o.position[0]; dv.py = o.position[1]; dv.pz = o.position[2];
@@ -263,6 +315,10 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 			}
 		}
 		if (depth_max > scene_max_depth) scene_max_depth = depth_max;
+		if (!(on[0].left == -1 && on[0].right == -1)) {
+			dv.big_slot = num_big;
+			big_object[num_big++] = oi;
+		}
 	}
 
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -272,6 +328,8 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	s->num_objects = d->num_objects;
 	s->max_depth = scene_max_depth;
 	s->num_dev_triangles = (int)(geom.size() / 3);
+	s->num_big = num_big;
+	for (int k = 0; k < num_big; ++k) s->big_object[k] = big_object[k];
 	memset(&s->dev, 0, sizeof(s->dev));
 	int rc;
 #define UP(vec, field) \
@@ -367,6 +425,7 @@ extern "C" int ptx_render_cleanup(PtxCtx* ctx) {
 	hipSetDevice(ctx->device);
 	hipStreamSynchronize(ctx->stream);
 	if (ctx->owns_accum && ctx->accum) hipFree(ctx->accum);
+	wf_free(ctx);
 	ctx->accum = NULL;
 	ctx->owns_accum = false;
 	ctx->has_render = false;
@@ -398,17 +457,70 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		return fail(PTX_E_INVALID, "sample range [%d,+%d)", first_sample, num_samples);
 	if (num_samples == 0) return PTX_OK;
 	HIP_TRY(hipSetDevice(ctx->device));
-	const int tiles_x = (ctx->cam.width + 15) / 16, tiles_y = (ctx->cam.height + 15) / 16;
-	const dim3 grid((unsigned)(tiles_x * tiles_y)), block(PT_BLOCK);
-	const size_t lds = stack_lds_bytes(scene);
 	const uint32_t k0 = (uint32_t)(seed & 0xffffffffu), k1 = (uint32_t)(seed >> 32);
-	if (ctx->cam.aabb_mode)
-		hipLaunchKernelGGL(render_kernel<PT_F_DEBUGMASK>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
-	else if (collect_stats)
-		hipLaunchKernelGGL(render_kernel<PT_F_STATS>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
-	else
-		hipLaunchKernelGGL(render_kernel<0>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
-	HIP_TRY(hipGetLastError());
+	if (ctx->cam.aabb_mode || ctx->force_megakernel || ctx->cam.max_bounces > PT_WF_MAX_BOUNCES) {
+		// one-lane-per-pixel megakernel: kept for the AABB debug view (its mask is a float product
+		// taken in object order) and as an A/B reference (PTX_MEGAKERNEL=1)
+		const int tiles_x = (ctx->cam.width + 15) / 16, tiles_y = (ctx->cam.height + 15) / 16;
+		const dim3 grid((unsigned)(tiles_x * tiles_y)), block(PT_BLOCK);
+		const size_t lds = stack_lds_bytes(scene);
+		if (ctx->cam.aabb_mode)
+			hipLaunchKernelGGL(render_kernel<PT_F_DEBUGMASK>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
+		else if (collect_stats)
+			hipLaunchKernelGGL(render_kernel<PT_F_STATS>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
+		else
+			hipLaunchKernelGGL(render_kernel<0>, grid, block, lds, ctx->stream, scene->dev, ctx->cam, ctx->accum, first_sample, num_samples, k0, k1, ctx->d_stats);
+		HIP_TRY(hipGetLastError());
+		return PTX_OK;
+	}
+
+	// ---- wavefront pipeline (pt_wavefront.h) ----------------------------------------------------
+	const int W = ctx->cam.width, Hh = ctx->cam.height;
+	const int tiles_x = (W + 7) / 8, tiles_y = (Hh + 7) / 8;
+	const size_t npt = (size_t)tiles_x * tiles_y * 64, npix = (size_t)W * Hh;
+	int batch = ctx->wf_batch;
+	while (batch > 1 && npt * (size_t)batch > ((size_t)1 << 27)) batch >>= 1;
+	if (batch > num_samples) batch = num_samples;
+	rc = wf_ensure(ctx, npt * (size_t)batch, npix * (size_t)batch, scene->num_big);
+	if (rc != PTX_OK) return rc;
+	const int cus = 256;
+	const int maxb = ctx->cam.max_bounces;
+	for (int s0 = first_sample; s0 < first_sample + num_samples; s0 += batch) {
+		const int b = (first_sample + num_samples - s0) < batch ? (first_sample + num_samples - s0) : batch;
+		WfParams wp = ctx->wf;
+		wp.stats = ctx->d_stats;
+		wp.first_sample = s0;
+		wp.batch = b;
+		wp.npt = (int)npt;
+		wp.tiles_x = tiles_x;
+		wp.npix = (int)npix;
+		wp.n_total = (int)(npt * (size_t)b);
+		wp.k0 = k0; wp.k1 = k1;
+		HIP_TRY(hipMemsetAsync(wp.counters, 0, (size_t)(maxb + 1) * (1 + PT_MAX_BIG) * sizeof(int), ctx->stream));
+		for (int bounce = 0; bounce <= maxb; ++bounce) {
+			wp.bounce = bounce;
+			wp.is_last = bounce == maxb ? 1 : 0;
+			size_t blocks = ((size_t)wp.n_total + PT_BLOCK - 1) / PT_BLOCK;
+			if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
+			if (collect_stats)
+				hipLaunchKernelGGL(wf_segment_kernel<PT_F_STATS>, dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+			else
+				hipLaunchKernelGGL(wf_segment_kernel<0>, dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+			HIP_TRY(hipGetLastError());
+			if (wp.is_last) break;
+			for (int k = 0; k < scene->num_big; ++k) {
+				size_t tb = blocks < (size_t)cus * 8 ? blocks : (size_t)cus * 8;
+				if (collect_stats)
+					hipLaunchKernelGGL(wf_traverse_kernel<PT_F_STATS>, dim3((unsigned)tb), dim3(PT_BLOCK), stack_lds_bytes(scene), ctx->stream, scene->dev, wp, scene->big_object[k], k);
+				else
+					hipLaunchKernelGGL(wf_traverse_kernel<0>, dim3((unsigned)tb), dim3(PT_BLOCK), stack_lds_bytes(scene), ctx->stream, scene->dev, wp, scene->big_object[k], k);
+				HIP_TRY(hipGetLastError());
+			}
+		}
+		hipLaunchKernelGGL(wf_accumulate_kernel, dim3((unsigned)((npix + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream,
+		                   ctx->accum, (const float4*)wp.rad, (int)npix, b);
+		HIP_TRY(hipGetLastError());
+	}
 	return PTX_OK;
 }
 
