@@ -111,102 +111,127 @@ PT_DEV bool sphere_test(const Ray& r, float rad, f3 center, f3& hit_point, f3& h
 // iteration. A node record is fetched whole (4 x 16 B, one 64-B line) before the leaf/inner decision
 // so the decision does not add a dependent round trip; the next triangle is fetched while the
 // current one is tested.
+struct TravState {
+	int curr, sp;       // current node (scene-global, -1 = none) and number of stack entries
+	int tri;            // best triangle so far (device index), -1 = none
+	float tmin, bu, bv;
+	bool intersects;
+};
+
+PT_DEV void trav_begin(TravState& ts, const DevObject& ob) {
+	ts.curr = ob.root_node;
+	ts.sp = 0;
+	ts.tri = -1;
+	ts.tmin = __builtin_huge_valf();
+	ts.bu = ts.bv = 0.0f;
+	ts.intersects = false;
+}
+
+// One unit of traversal: descend to the next leaf, test its triangles, pop. Returns true when the
+// traversal is finished (stack empty). Running it to completion is rayIntersectsKDNodeLOOP.
+template <int FLAGS>
+PT_DEV bool traverse_step(const DevScene& sc, const DevObject& ob, int obj_index, const Ray& ray, int* stack,
+                          int stride, TravState& ts, TraceCounters& cnt, float& dbg, uint32_t& steps) {
+	const float4* __restrict__ nodes = sc.nodes;
+	const float4* __restrict__ geom = sc.tri_geom;
+	int curr = ts.curr, sp = ts.sp;
+	int first = 0, count = -1;
+	// ---- descend until a leaf is reached or the traversal is over -----------------------
+	while (curr >= 0) {
+		const float4 q3 = nodes[4 * curr + 3];
+		const float4 q0 = nodes[4 * curr + 0];
+		const float4 q1 = nodes[4 * curr + 1];
+		const float4 q2 = nodes[4 * curr + 2];
+		if (FLAGS & PT_F_STATS) steps++;
+		const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+		if (left == -1 && right == -1) {
+			first = __float_as_int(q3.z);
+			count = __float_as_int(q3.w);
+			if (FLAGS & PT_F_STATS) {
+				cnt.n_leaf++;
+				cnt.n_tri += (uint32_t)count;
+				fnv_word(cnt.leaf_hash, (uint32_t)obj_index);
+				fnv_word(cnt.leaf_hash, (uint32_t)(curr - ob.first_node));
+			}
+			break;
+		}
+		// inner node: test both child boxes (stored in this record)
+		if (FLAGS & PT_F_STATS) cnt.n_inner++;
+		float left_dist = __builtin_huge_valf(), right_dist = __builtin_huge_valf();
+		bool left_res = false, right_res = false;
+		if (left != -1) {
+			if (FLAGS & PT_F_STATS) cnt.n_box++;
+			left_res = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ray, left_dist) && (left_dist < ts.tmin);
+		}
+		if (right != -1) {
+			if (FLAGS & PT_F_STATS) cnt.n_box++;
+			right_res = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ray, right_dist) && (right_dist < ts.tmin);
+		}
+		if (left_res && right_res) {
+			// nearer child first; tie -> left first (reference :183-187)
+			int further = right;
+			int next = right;
+			if (left_dist > right_dist) further = left; else next = left;
+			stack[sp * stride] = further;
+			++sp;
+			curr = next;
+			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.9025f;
+		} else if (left_res) {
+			curr = left;
+			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
+		} else if (right_res) {
+			curr = right;
+			if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
+		} else {
+			if (sp == 0) { curr = -1; break; }
+			--sp;
+			curr = stack[sp * stride];
+		}
+	}
+	if (count < 0) { ts.curr = -1; ts.sp = 0; return true; } // no leaf: traversal finished
+
+	// ---- leaf: test all triangles of the node, in list order -----------------------------
+	if (count > 0) {
+		float4 g0 = geom[3 * first + 0], g1 = geom[3 * first + 1], g2 = geom[3 * first + 2];
+		for (int i = 0; i < count; ++i) {
+			float4 n0 = g0, n1 = g1, n2 = g2;
+			if (i + 1 < count) {
+				n0 = geom[3 * (first + i + 1) + 0];
+				n1 = geom[3 * (first + i + 1) + 1];
+				n2 = geom[3 * (first + i + 1) + 2];
+			}
+			if (FLAGS & PT_F_STATS) steps++;
+			float t, u, v;
+			if (tri_test(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
+				ts.intersects = true;
+				if (t < ts.tmin) {
+					ts.tmin = t;
+					ts.tri = first + i;
+					ts.bu = u;
+					ts.bv = v;
+				}
+			}
+			g0 = n0; g1 = n1; g2 = n2;
+		}
+	}
+	// pop
+	if (sp == 0) { ts.curr = -1; ts.sp = 0; return true; }
+	--sp;
+	ts.curr = stack[sp * stride];
+	ts.sp = sp;
+	return false;
+}
+
 template <int FLAGS>
 PT_DEV bool traverse_nodes(const DevScene& sc, const DevObject& ob, int obj_index, const Ray& ray,
                            int* stack, int stride, float& tmin, int& best_tri, float& bu, float& bv,
                            TraceCounters& cnt, float& dbg, uint32_t& steps) {
-	bool intersects = false;
-	int sp = 0;          // number of entries on the stack
-	int curr = ob.root_node;
-	const float4* __restrict__ nodes = sc.nodes;
-	const float4* __restrict__ geom = sc.tri_geom;
-
-	for (;;) {
-		int first = 0, count = -1;
-		// ---- descend until a leaf is reached or the traversal is over -----------------------
-		while (curr >= 0) {
-			const float4 q3 = nodes[4 * curr + 3];
-			const float4 q0 = nodes[4 * curr + 0];
-			const float4 q1 = nodes[4 * curr + 1];
-			const float4 q2 = nodes[4 * curr + 2];
-			if (FLAGS & PT_F_STATS) steps++;
-			const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-			if (left == -1 && right == -1) {
-				first = __float_as_int(q3.z);
-				count = __float_as_int(q3.w);
-				if (FLAGS & PT_F_STATS) {
-					cnt.n_leaf++;
-					cnt.n_tri += (uint32_t)count;
-					fnv_word(cnt.leaf_hash, (uint32_t)obj_index);
-					fnv_word(cnt.leaf_hash, (uint32_t)(curr - ob.first_node));
-				}
-				break;
-			}
-			// inner node: test both child boxes (stored in this record)
-			if (FLAGS & PT_F_STATS) cnt.n_inner++;
-			float left_dist = __builtin_huge_valf(), right_dist = __builtin_huge_valf();
-			bool left_res = false, right_res = false;
-			if (left != -1) {
-				if (FLAGS & PT_F_STATS) cnt.n_box++;
-				left_res = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ray, left_dist) && (left_dist < tmin);
-			}
-			if (right != -1) {
-				if (FLAGS & PT_F_STATS) cnt.n_box++;
-				right_res = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ray, right_dist) && (right_dist < tmin);
-			}
-			if (left_res && right_res) {
-				// nearer child first; tie -> left first (reference :183-187)
-				int further = right;
-				int next = right;
-				if (left_dist > right_dist) further = left; else next = left;
-				stack[sp * stride] = further;
-				++sp;
-				curr = next;
-				if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.9025f;
-			} else if (left_res) {
-				curr = left;
-				if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
-			} else if (right_res) {
-				curr = right;
-				if (FLAGS & PT_F_DEBUGMASK) dbg *= 0.95f;
-			} else {
-				if (sp == 0) { curr = -1; break; }
-				--sp;
-				curr = stack[sp * stride];
-			}
-		}
-		if (count < 0) break; // no leaf: traversal finished
-
-		// ---- leaf: test all triangles of the node, in list order -----------------------------
-		if (count > 0) {
-			float4 g0 = geom[3 * first + 0], g1 = geom[3 * first + 1], g2 = geom[3 * first + 2];
-			for (int i = 0; i < count; ++i) {
-				float4 n0 = g0, n1 = g1, n2 = g2;
-				if (i + 1 < count) {
-					n0 = geom[3 * (first + i + 1) + 0];
-					n1 = geom[3 * (first + i + 1) + 1];
-					n2 = geom[3 * (first + i + 1) + 2];
-				}
-				if (FLAGS & PT_F_STATS) steps++;
-				float t, u, v;
-				if (tri_test(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
-					intersects = true;
-					if (t < tmin) {
-						tmin = t;
-						best_tri = first + i;
-						bu = u;
-						bv = v;
-					}
-				}
-				g0 = n0; g1 = n1; g2 = n2;
-			}
-		}
-		// pop
-		if (sp == 0) break;
-		--sp;
-		curr = stack[sp * stride];
-	}
-	return intersects;
+	TravState ts;
+	trav_begin(ts, ob);
+	ts.tmin = tmin;
+	while (!traverse_step<FLAGS>(sc, ob, obj_index, ray, stack, stride, ts, cnt, dbg, steps)) {}
+	if (ts.tri >= 0) { tmin = ts.tmin; best_tri = ts.tri; bu = ts.bu; bv = ts.bv; }
+	return ts.intersects;
 }
 
 // root box test (reference :130-135) + traversal

@@ -32,7 +32,8 @@
 #pragma once
 #include "pt_kernels.h"
 
-#define PT_MAX_BIG 32   // = PTX_MAX_OBJECTS: every mesh may be a multi-node one
+#define PT_MAX_BIG 31   // multi-node meshes with a traversal queue (flag bits 1..31 of a 32-bit word)
+#define WF_ROUNDS 4
 #define PT_WF_MAX_BOUNCES 64
 
 struct WfParams {
@@ -47,6 +48,7 @@ struct WfParams {
 	int tiles_x, npix, n_total;
 	uint32_t k0, k1;
 	int bounce, is_last;
+	int num_big;
 };
 
 #define WF_CNT(wp, b, k) ((wp).counters[(b) * (1 + PT_MAX_BIG) + (k)])
@@ -130,8 +132,20 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCa
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
 	uint64_t n_rays = 0, n_paths = 0, c_hm = 0, c_hs = 0, c_ht = 0;
 
-	for (int i0 = (int)blockIdx.x * PT_BLOCK + (tid & ~63); i0 < n_in; i0 += (int)gridDim.x * PT_BLOCK) {
-		const int i = i0 + lane;
+	// List appends (next live list, traversal queues) are aggregated over WF_ROUNDS x 256 paths per
+	// workgroup: ONE atomic per list per 1024 paths. (One atomic per wave serialised the whole chip on
+	// a single counter address: 91 % of this kernel's wave time was spent waiting, profiles/r01b.)
+	__shared__ int sh_path[WF_ROUNDS * PT_BLOCK];
+	__shared__ uint32_t sh_flags[WF_ROUNDS * PT_BLOCK];
+	__shared__ int sh_cnt[1 + PT_MAX_BIG][WF_ROUNDS * (PT_BLOCK / 64)];
+	__shared__ int sh_base[1 + PT_MAX_BIG];
+	const int wave = tid >> 6;
+	const int nlists = 1 + wp.num_big;
+
+	for (int blk0 = (int)blockIdx.x * (WF_ROUNDS * PT_BLOCK); blk0 < n_in; blk0 += (int)gridDim.x * (WF_ROUNDS * PT_BLOCK)) {
+	for (int round = 0; round < WF_ROUNDS; ++round) {
+		const int i = blk0 + round * PT_BLOCK + tid;
+		uint32_t flags = 0;
 		bool alive = i < n_in;
 		int path = 0;
 		if (alive) path = bounce == 0 ? i : live_in[i];
@@ -234,8 +248,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCa
 					enter = box_test(ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], ray, rd);
 				}
 				if (ob.big_slot >= 0) {
-					const int slot = wave_append(&WF_CNT(wp, bounce, 1 + ob.big_slot), enter);
-					if (slot >= 0) wp.queue[ob.big_slot][slot] = path;
+					if (enter) flags |= 2u << ob.big_slot;
 				} else if (enter) {
 					float tmin = __builtin_huge_valf(), bu = 0.0f, bv = 0.0f;
 					int tri = -1;
@@ -254,13 +267,49 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCa
 			wp.s2[path] = make_float4(mask.x, mask.y, mask.z, __int_as_float(best_obj));
 			wp.s3[path] = make_float4(__int_as_float(best_tri), b_u, b_v, 0.0f);
 		}
-		const int slot = wave_append(&WF_CNT(wp, bounce, 0), alive);
-		if (slot >= 0) live_out[slot] = path;
+		if (alive) flags |= 1u;
+		sh_path[round * PT_BLOCK + tid] = path;
+		sh_flags[round * PT_BLOCK + tid] = flags;
+		for (int L = 0; L < nlists; ++L) {
+			const unsigned long long m = __ballot((flags >> L) & 1u);
+			if (lane == 0) sh_cnt[L][round * (PT_BLOCK / 64) + wave] = (int)__popcll(m);
+		}
+	} // rounds
+		__syncthreads();
+		if (tid < nlists) {
+			int total = 0;
+			for (int j = 0; j < WF_ROUNDS * (PT_BLOCK / 64); ++j) {
+				const int c = sh_cnt[tid][j];
+				sh_cnt[tid][j] = total;
+				total += c;
+			}
+			sh_base[tid] = total ? atomicAdd(&WF_CNT(wp, bounce, tid), total) : 0;
+		}
+		__syncthreads();
+		for (int round = 0; round < WF_ROUNDS; ++round) {
+			const uint32_t f = sh_flags[round * PT_BLOCK + tid];
+			const int p = sh_path[round * PT_BLOCK + tid];
+			for (int L = 0; L < nlists; ++L) {
+				const bool on = (f >> L) & 1u;
+				const unsigned long long m = __ballot(on);
+				if (on) {
+					const int slot = sh_base[L] + sh_cnt[L][round * (PT_BLOCK / 64) + wave] + (int)__popcll(m & ((1ull << lane) - 1ull));
+					if (L == 0) live_out[slot] = p; else wp.queue[L - 1][slot] = p;
+				}
+			}
+		}
+		__syncthreads();
 	}
 	stats_flush(wp.stats, cnt, n_rays, n_paths, c_hm, c_hs, c_ht, 0, 0, (FLAGS & PT_F_STATS) != 0);
 }
 
 // KD traversal of the rays queued for one multi-node mesh; merges into the path's closest-hit record.
+//
+// Persistent waves with lane refill: every wave owns one contiguous chunk of the queue and a
+// wave-private cursor (no atomics). A lane whose ray has finished takes the next ray of the chunk at
+// the top of the next traversal step, so a long ray no longer holds 63 finished lanes hostage
+// (measured before: 29 % useful lanes in this kernel). Chunks are large (queue / resident waves,
+// ~1000+ rays), which evens out the total work per wave.
 template <int FLAGS>
 __global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
 	extern __shared__ int lds_stack[];
@@ -272,33 +321,57 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(DevScene sc, WfPa
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
 	uint64_t act = 0, tot = 0;
 
-	for (int i0 = (int)blockIdx.x * PT_BLOCK + (tid & ~63); i0 < n; i0 += (int)gridDim.x * PT_BLOCK) {
-		const int i = i0 + lane;
+	const long long nw = (long long)gridDim.x * (PT_BLOCK / 64);
+	const long long gw = (long long)blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
+	int next = (int)(((long long)n * gw) / nw);          // wave-uniform cursor into this wave's chunk
+	const int hi = (int)(((long long)n * (gw + 1)) / nw);
+
+	bool active = false;
+	int path = 0;
+	float cur_d = 0.0f;
+	Ray ray;
+	TravState ts;
+	ts.curr = -1; ts.sp = 0; ts.tri = -1; ts.tmin = 0.0f; ts.bu = ts.bv = 0.0f; ts.intersects = false;
+
+	for (;;) {
+		// ---- refill idle lanes from the wave's chunk ----
+		const unsigned long long idle = __ballot(!active);
+		if (idle != 0ull && next < hi) {
+			const int mine = next + (int)__popcll(idle & ((1ull << lane) - 1ull));
+			if (!active && mine < hi) {
+				path = queue[mine];
+				const float4 a0 = wp.s0[path], a1 = wp.s1[path];
+				init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
+				cur_d = a0.w;
+				trav_begin(ts, ob);
+				active = true;
+			}
+			next += (int)__popcll(idle);
+		}
+		if (__ballot(active) == 0ull) break;
+
 		uint32_t steps = 0;
-		if (i < n) {
-			const int path = queue[i];
-			const float4 a0 = wp.s0[path], a1 = wp.s1[path];
-			Ray ray;
-			init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
-			float tmin = __builtin_huge_valf(), bu = 0.0f, bv = 0.0f, dbg = 1.0f;
-			int tri = -1;
-			const bool hit = traverse_nodes<FLAGS>(sc, ob, obj_index, ray, stack, PT_BLOCK, tmin, tri, bu, bv, cnt, dbg, steps);
-			if (hit && tri >= 0) {
-				const f3 p = ray.o + tmin * ray.d;
-				const float d = length3(p - ray.o);
-				const int cur_obj = __float_as_int(wp.s2[path].w);
-				const float cur_d = a0.w;
-				// strict '<' in object order == smaller distance, ties to the lower object index
-				if (d < cur_d || (d == cur_d && cur_obj >= 0 && obj_index < cur_obj)) {
-					wp.s0[path].w = d;
-					wp.s1[path].w = tmin;
-					wp.s2[path].w = __int_as_float(obj_index);
-					wp.s3[path] = make_float4(__int_as_float(tri), bu, bv, 0.0f);
+		if (active) {
+			float dbg = 1.0f;
+			const bool finished = traverse_step<FLAGS>(sc, ob, obj_index, ray, stack, PT_BLOCK, ts, cnt, dbg, steps);
+			if (finished) {
+				if (ts.intersects && ts.tri >= 0) {
+					const f3 p = ray.o + ts.tmin * ray.d;
+					const float d = length3(p - ray.o);
+					const int cur_obj = __float_as_int(wp.s2[path].w);
+					// strict '<' in object order == smaller distance, ties to the lower object index
+					if (d < cur_d || (d == cur_d && cur_obj >= 0 && obj_index < cur_obj)) {
+						wp.s0[path].w = d;
+						wp.s1[path].w = ts.tmin;
+						wp.s2[path].w = __int_as_float(obj_index);
+						wp.s3[path] = make_float4(__int_as_float(ts.tri), ts.bu, ts.bv, 0.0f);
+					}
 				}
+				active = false;
 			}
 		}
 		if (FLAGS & PT_F_STATS) {
-			// lane utilisation of the traversal: own steps vs 64 x the slowest lane of this round
+			// lane utilisation of the traversal: own steps vs 64 x the slowest lane of this step
 			uint32_t mx = steps;
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) {

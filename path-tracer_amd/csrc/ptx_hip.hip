@@ -215,7 +215,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	geom.reserve((size_t)d->num_leaf_tris * 3);
 	shade.reserve((size_t)d->num_leaf_tris * 4);
 	int scene_max_depth = 0;
-	int num_big = 0, big_object[PT_MAX_BIG];
+	int num_big = 0, big_object[PT_MAX_BIG + 1];
 
 	for (int m = 0; m < d->num_materials; ++m) {
 		const PtxMaterial& pm = d->materials[m];
@@ -316,8 +316,8 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 		}
 		if (depth_max > scene_max_depth) scene_max_depth = depth_max;
 		if (!(on[0].left == -1 && on[0].right == -1)) {
-			dv.big_slot = num_big;
-			big_object[num_big++] = oi;
+			if (num_big < PT_MAX_BIG) { dv.big_slot = num_big; big_object[num_big] = oi; }
+			num_big++; // more than PT_MAX_BIG multi-node meshes: the scene renders through the megakernel
 		}
 	}
 
@@ -329,7 +329,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	s->max_depth = scene_max_depth;
 	s->num_dev_triangles = (int)(geom.size() / 3);
 	s->num_big = num_big;
-	for (int k = 0; k < num_big; ++k) s->big_object[k] = big_object[k];
+	for (int k = 0; k < num_big && k < PT_MAX_BIG; ++k) s->big_object[k] = big_object[k];
 	memset(&s->dev, 0, sizeof(s->dev));
 	int rc;
 #define UP(vec, field) \
@@ -458,7 +458,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	if (num_samples == 0) return PTX_OK;
 	HIP_TRY(hipSetDevice(ctx->device));
 	const uint32_t k0 = (uint32_t)(seed & 0xffffffffu), k1 = (uint32_t)(seed >> 32);
-	if (ctx->cam.aabb_mode || ctx->force_megakernel || ctx->cam.max_bounces > PT_WF_MAX_BOUNCES) {
+	if (ctx->cam.aabb_mode || ctx->force_megakernel || ctx->cam.max_bounces > PT_WF_MAX_BOUNCES || scene->num_big > PT_MAX_BIG) {
 		// one-lane-per-pixel megakernel: kept for the AABB debug view (its mask is a float product
 		// taken in object order) and as an A/B reference (PTX_MEGAKERNEL=1)
 		const int tiles_x = (ctx->cam.width + 15) / 16, tiles_y = (ctx->cam.height + 15) / 16;
@@ -481,7 +481,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	int batch = ctx->wf_batch;
 	while (batch > 1 && npt * (size_t)batch > ((size_t)1 << 27)) batch >>= 1;
 	if (batch > num_samples) batch = num_samples;
-	rc = wf_ensure(ctx, npt * (size_t)batch, npix * (size_t)batch, scene->num_big);
+	rc = wf_ensure(ctx, (npt * (size_t)batch + WF_ROUNDS * PT_BLOCK), npix * (size_t)batch, scene->num_big);
 	if (rc != PTX_OK) return rc;
 	const int cus = 256;
 	const int maxb = ctx->cam.max_bounces;
@@ -496,11 +496,12 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		wp.npix = (int)npix;
 		wp.n_total = (int)(npt * (size_t)b);
 		wp.k0 = k0; wp.k1 = k1;
+		wp.num_big = scene->num_big;
 		HIP_TRY(hipMemsetAsync(wp.counters, 0, (size_t)(maxb + 1) * (1 + PT_MAX_BIG) * sizeof(int), ctx->stream));
 		for (int bounce = 0; bounce <= maxb; ++bounce) {
 			wp.bounce = bounce;
 			wp.is_last = bounce == maxb ? 1 : 0;
-			size_t blocks = ((size_t)wp.n_total + PT_BLOCK - 1) / PT_BLOCK;
+			size_t blocks = ((size_t)wp.n_total + WF_ROUNDS * PT_BLOCK - 1) / (WF_ROUNDS * PT_BLOCK);
 			if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
 			if (collect_stats)
 				hipLaunchKernelGGL(wf_segment_kernel<PT_F_STATS>, dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
@@ -509,7 +510,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 			HIP_TRY(hipGetLastError());
 			if (wp.is_last) break;
 			for (int k = 0; k < scene->num_big; ++k) {
-				size_t tb = blocks < (size_t)cus * 8 ? blocks : (size_t)cus * 8;
+				const size_t tb = (size_t)cus * 8; // persistent waves, each owns queue/waves entries
 				if (collect_stats)
 					hipLaunchKernelGGL(wf_traverse_kernel<PT_F_STATS>, dim3((unsigned)tb), dim3(PT_BLOCK), stack_lds_bytes(scene), ctx->stream, scene->dev, wp, scene->big_object[k], k);
 				else
