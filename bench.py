@@ -11,9 +11,11 @@ every rank renders its own disjoint sample range per step (weak scaling, no data
 collective) and ONE all-reduce (RCCL) of the float accumulation buffers closes the timed region.
 
 Prints one JSON line (rank 0) with the contract fields plus
-  "roofline"      for the dominant kernel, render_kernel: algorithmic bytes per launch (DESIGN.md
-                  "bytes per ray", counters measured on the same samples by the counting variant)
-                  / mean launch duration from HIP events on the library's stream
+  "roofline"      for the dominant kernel, wf_traverse_kernel (KD traversal + ray/triangle tests of
+                  the rays queued for a multi-node mesh): algorithmic bytes per launch (DESIGN.md
+                  "bytes per traversal"; counters measured on the SAME samples by the counting
+                  variant) / mean launch duration from HIP event pairs recorded around every launch
+                  of the timed region on the library's stream (ptx_profile_enable / ptx_profile_get)
   "cpu_baseline"  the CPU oracle (a straight multithreaded port, oracle/) timed on this box's host
                   cores on a bounded sample of the same workload.
 """
@@ -32,13 +34,30 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def bytes_and_flops(st):
-    """Algorithmic bytes / flops of a set of path segments."""
-    rays = st["rays"]
-    b = (56 * st["n_inner"] + 40 * st["n_tri"] + 16 * st["n_sphere"] + 64 * rays
-         + 112 * st["hit_mesh"] + 16 * st["hit_textured"])
-    f = (22 * st["n_box"] + 48 * st["n_tri"] + 20 * st["n_sphere"] + 130 * (st["hit_mesh"] + st["hit_sphere"]))
+def traverse_bytes_and_flops(st):
+    """Algorithmic bytes / flops of wf_traverse_kernel (DESIGN.md "bytes per traversal").
+
+    per inner-node visit: both children's boxes (12 floats) + links/leaf range (4 ints) = 64 B
+    per triangle test:    a, e1, e2 (9 floats) + primitive id                          = 40 B
+    per queued ray:       queue entry 4 + origin/direction 24 + hit record read and write 16+16 = 60 B
+    flops: 2 slab tests per inner visit (2 x 22), Moller-Trumbore 48 per triangle, ray set-up 10.
+    """
+    b = 64 * st["trav_inner"] + 40 * st["trav_tri"] + 60 * st["trav_rays"]
+    f = 22 * st["trav_box"] + 48 * st["trav_tri"] + 10 * st["trav_rays"]
     return b, f
+
+
+def load_traffic(workload_key):
+    """HBM bytes per wf_traverse_kernel launch from the committed PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_wavefront_hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if d.get("workload") == workload_key:
+            return d.get("traverse_hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def main():
@@ -108,6 +127,7 @@ def main():
     barrier()
 
     kernel_ms = C.c_float(0)
+    pt.check(L.ptx_profile_enable(ctx, 1))
     t0 = time.perf_counter()
     pt.check(L.ptx_timer_begin(ctx))
     for i in range(args.warmup, args.warmup + args.steps):
@@ -118,6 +138,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    trav_ms, seg_ms = C.c_float(0), C.c_float(0)
+    trav_n, seg_n = C.c_int32(0), C.c_int32(0)
+    pt.check(L.ptx_profile_get(ctx, C.byref(trav_ms), C.byref(trav_n), C.byref(seg_ms), C.byref(seg_n)))
+    pt.check(L.ptx_profile_enable(ctx, 0))
     pt.check(L.ptx_stats_get(ctx, C.byref(stats)))
     rays_local = torch.tensor([float(stats.rays), elapsed, float(kernel_ms.value)], dtype=torch.float64,
                               device=f"cuda:{local_rank}")
@@ -137,25 +161,31 @@ def main():
 
     # ---- roofline leg (rank 0): counters of the SAME samples from the counting variant --------------
     pt.check(L.ptx_stats_reset(ctx))
-    pt.check(L.ptx_render_samples(ctx, scene, (args.warmup * world + rank) * spp, spp, args.seed, 1))
+    for i in range(args.warmup, args.warmup + args.steps):
+        pt.check(L.ptx_render_samples(ctx, scene, (i * world + rank) * spp, spp, args.seed, 1))
     pt.check(L.ptx_render_sync(ctx))
     cst = pt.PtxStats()
     pt.check(L.ptx_stats_get(ctx, C.byref(cst)))
     cd = cst.as_dict()
-    b_launch, f_launch = bytes_and_flops(cd)
-    launch_ms = float(kernel_ms.value) / args.steps
-    achieved_gbs = b_launch / (launch_ms * 1e-3) / 1e9
-    achieved_tflops = f_launch / (launch_ms * 1e-3) / 1e12
-    lane_frac = cd["lane_steps_active"] / max(1, cd["lane_steps_total"])
+    b_total, f_total = traverse_bytes_and_flops(cd)
+    n_launch = max(1, trav_n.value)
+    launch_ms = float(trav_ms.value) / n_launch
+    b_launch = b_total / n_launch
+    achieved_gbs = b_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    achieved_tflops = f_total / n_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+    tr = max(1, cd["trav_rays"])
+    workload_key = f"{args.scene}:{cam.width}x{cam.height}:spp{spp}:tex{args.textures}"
     roofline = {
-        "kernel": "render_kernel<0>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": None,
-        "launch_ms": round(launch_ms, 3), "bytes_per_launch": b_launch, "rays_per_launch": cd["rays"],
-        "bytes_per_ray": round(b_launch / max(1, cd["rays"]), 1),
+        "kernel": "wf_traverse_kernel<0,1,3>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": load_traffic(workload_key),
+        "launch_ms": round(launch_ms, 4), "launches": trav_n.value, "bytes_per_launch": round(b_launch),
+        "traversals_per_launch": round(cd["trav_rays"] / n_launch), "bytes_per_traversal": round(b_total / tr, 1),
+        "share_of_step": round(float(trav_ms.value) / max(1e-9, float(kernel_ms.value)), 4),
         "valu": {"achieved": round(achieved_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(achieved_tflops / VALU_PEAK_TFLOPS, 5), "flops_per_ray": round(f_launch / max(1, cd["rays"]), 1),
-                 "active_lane_frac_segments": round(lane_frac, 4)},
-        "per_ray": {k: round(cd[k] / max(1, cd["rays"]), 3) for k in ("n_inner", "n_box", "n_tri", "n_sphere", "n_leaf")},
+                 "frac": round(achieved_tflops / VALU_PEAK_TFLOPS, 5), "flops_per_traversal": round(f_total / tr, 1)},
+        "per_traversal": {k: round(cd[k] / tr, 3) for k in ("trav_inner", "trav_box", "trav_tri", "trav_leaf")},
+        "segment_kernel": {"launch_ms": round(float(seg_ms.value) / max(1, seg_n.value), 4), "launches": seg_n.value},
+        "step_kernel_ms": round(float(kernel_ms.value) / args.steps, 3),
     }
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------

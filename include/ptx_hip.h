@@ -137,7 +137,10 @@ typedef struct PtxStats {
 	uint64_t paths;         /* (pixel, sample) paths started */
 	uint64_t n_inner, n_box, n_tri, n_sphere, n_leaf;   /* filled by the *_stats render variant only */
 	uint64_t hit_mesh, hit_sphere, hit_textured;        /* idem */
-	uint64_t lane_steps_active, lane_steps_total;       /* idem: active lanes / (64 x wave iterations) of the segment loop */
+	uint64_t lane_steps_active, lane_steps_total;       /* idem: traversal steps done by lanes / (64 x the slowest lane's steps per wave round) */
+	/* idem, restricted to multi-node meshes (what wf_traverse_kernel does): rays entering their root box,
+	 * inner-node steps, box tests below the root, triangle tests, leaves */
+	uint64_t trav_rays, trav_inner, trav_box, trav_tri, trav_leaf;
 } PtxStats;
 
 /* BSDF known-answer entry (parity for surfaces.cuh). */
@@ -200,6 +203,15 @@ int ptx_accum_upload(PtxCtx* ctx, const float* rgba_host);
 int ptx_tonemap(PtxCtx* ctx, int iter, float gamma, unsigned char* rgba8_host);
 int ptx_stats_get(PtxCtx* ctx, PtxStats* out);
 int ptx_stats_reset(PtxCtx* ctx);
+/* Diagnostics of the LAST wavefront pass (no reference counterpart): per bounce b in [0, max_bounces],
+ * live_out[b] = paths still alive after bounce b's segment kernel, queued_out[b] = rays enqueued for
+ * KD traversal of multi-node meshes. Arrays of max_bounces + 1 entries. */
+int ptx_wavefront_counts(PtxCtx* ctx, int max_bounces, int32_t* live_out, int32_t* queued_out);
+/* Per-kernel-class timing of ptx_render_samples (HIP events around every launch on the context's stream;
+ * bench.py's roofline leg). enable != 0 starts collecting; ptx_profile_get waits for the stream, returns the
+ * summed durations / launch counts since enabling and clears them. No reference counterpart. */
+int ptx_profile_enable(PtxCtx* ctx, int enable);
+int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches, float* segment_ms, int32_t* segment_launches);
 /* HIP-event timer on the context's stream (for bench.py's roofline leg). */
 int ptx_timer_begin(PtxCtx* ctx);
 int ptx_timer_end(PtxCtx* ctx, float* elapsed_ms);

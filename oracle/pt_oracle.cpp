@@ -103,7 +103,7 @@ void init_ray(Ray* r, V3 orig, V3 dir) {
 	r->sign[2] = (r->inv.z < 0);
 }
 
-struct Counters { uint64_t n_inner, n_box, n_tri, n_leaf, n_sphere; uint32_t leaf_hash; };
+struct Counters { uint64_t n_inner, n_box, n_tri, n_leaf, n_sphere; uint64_t t_rays, t_inner, t_box, t_tri, t_leaf; uint32_t leaf_hash; };
 
 inline void fnv_word(uint32_t& h, uint32_t w) {
 	for (int i = 0; i < 4; ++i) { h ^= (w >> (8 * i)) & 0xFFu; h *= 16777619u; }
@@ -180,6 +180,9 @@ bool kdLoop(const PtxSceneDesc* sc, const PtxObject* ob, int obj_index, const Ra
 	cnt->n_box++;
 	if (!testBBox(flat_nodes[curr_idx].bmin, flat_nodes[curr_idx].bmax, ray, &dist)) return intersects;
 	*debug_mask *= 0.95f;
+	// counters restricted to multi-node meshes (root is not a leaf): what the GPU's traversal kernel does
+	const bool multi = !(flat_nodes[0].left == -1 && flat_nodes[0].right == -1);
+	if (multi) cnt->t_rays++;
 
 	int stack_pos = -1;
 	int stack[64];
@@ -190,6 +193,7 @@ bool kdLoop(const PtxSceneDesc* sc, const PtxObject* ob, int obj_index, const Ra
 		if (node.left == -1 && node.right == -1) {
 			float t, u, v;
 			cnt->n_leaf++;
+			if (multi) { cnt->t_leaf++; cnt->t_tri += (uint64_t)node.num_tris; }
 			fnv_word(cnt->leaf_hash, (uint32_t)obj_index);
 			fnv_word(cnt->leaf_hash, (uint32_t)curr_idx);
 			for (int i = 0; i < node.num_tris; i++) {
@@ -214,6 +218,7 @@ bool kdLoop(const PtxSceneDesc* sc, const PtxObject* ob, int obj_index, const Ra
 		}
 
 		cnt->n_inner++;
+		if (multi) { cnt->t_inner++; cnt->t_box += (node.left != -1) + (node.right != -1); }
 		float left_dist = HUGE_VALF, right_dist = HUGE_VALF;
 		bool left_res = false, right_res = false;
 		if (node.left != -1) {
@@ -806,6 +811,8 @@ extern "C" int orc_render(const PtxSceneDesc* scene, const PtxCamera* cam, int f
 			stats->n_inner += p.cnt.n_inner; stats->n_box += p.cnt.n_box; stats->n_tri += p.cnt.n_tri;
 			stats->n_sphere += p.cnt.n_sphere; stats->n_leaf += p.cnt.n_leaf;
 			stats->hit_mesh += p.hit_mesh; stats->hit_sphere += p.hit_sphere; stats->hit_textured += p.hit_tex;
+			stats->trav_rays += p.cnt.t_rays; stats->trav_inner += p.cnt.t_inner; stats->trav_box += p.cnt.t_box;
+			stats->trav_tri += p.cnt.t_tri; stats->trav_leaf += p.cnt.t_leaf;
 		}
 	}
 	return PTX_OK;

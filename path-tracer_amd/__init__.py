@@ -76,7 +76,8 @@ class PtxHit(C.Structure):
 class PtxStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "paths", "n_inner", "n_box", "n_tri", "n_sphere", "n_leaf",
                                           "hit_mesh", "hit_sphere", "hit_textured",
-                                          "lane_steps_active", "lane_steps_total")]
+                                          "lane_steps_active", "lane_steps_total",
+                                          "trav_rays", "trav_inner", "trav_box", "trav_tri", "trav_leaf")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -95,7 +96,7 @@ PTX_SYMBOLS = [
     "ptx_scene_upload", "ptx_scene_free", "ptx_scene_device_bytes", "ptx_render_init", "ptx_render_set_camera",
     "ptx_render_cleanup", "ptx_accum_clear", "ptx_render_samples", "ptx_render_sync", "ptx_accum_device_ptr",
     "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_stats_get", "ptx_stats_reset",
-    "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample",
+    "ptx_wavefront_counts", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample",
 ]
 
 _lib = None
@@ -138,6 +139,9 @@ def lib():
         L.ptx_tonemap.argtypes = [vp, i32, f32, C.POINTER(C.c_ubyte)]
         L.ptx_stats_get.argtypes = [vp, C.POINTER(PtxStats)]
         L.ptx_stats_reset.argtypes = [vp]
+        L.ptx_wavefront_counts.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.ptx_profile_enable.argtypes = [vp, i32]
+        L.ptx_profile_get.argtypes = [vp, fp, C.POINTER(C.c_int32), fp, C.POINTER(C.c_int32)]
         L.ptx_timer_begin.argtypes = [vp]
         L.ptx_timer_end.argtypes = [vp, fp]
         L.ptx_trace_rays.argtypes = [vp, vp, i32, fp, fp, i32, C.POINTER(PtxHit)]

@@ -129,7 +129,7 @@ PT_DEV void trav_begin(TravState& ts, const DevObject& ob) {
 
 // One unit of traversal: descend to the next leaf, test its triangles, pop. Returns true when the
 // traversal is finished (stack empty). Running it to completion is rayIntersectsKDNodeLOOP.
-template <int FLAGS>
+template <int FLAGS, int PREFETCH = 1>
 PT_DEV bool traverse_step(const DevScene& sc, const DevObject& ob, int obj_index, const Ray& ray, int* stack,
                           int stride, TravState& ts, TraceCounters& cnt, float& dbg, uint32_t& steps) {
 	const float4* __restrict__ nodes = sc.nodes;
@@ -191,27 +191,38 @@ PT_DEV bool traverse_step(const DevScene& sc, const DevObject& ob, int obj_index
 	if (count < 0) { ts.curr = -1; ts.sp = 0; return true; } // no leaf: traversal finished
 
 	// ---- leaf: test all triangles of the node, in list order -----------------------------
-	if (count > 0) {
-		float4 g0 = geom[3 * first + 0], g1 = geom[3 * first + 1], g2 = geom[3 * first + 2];
-		for (int i = 0; i < count; ++i) {
-			float4 n0 = g0, n1 = g1, n2 = g2;
-			if (i + 1 < count) {
-				n0 = geom[3 * (first + i + 1) + 0];
-				n1 = geom[3 * (first + i + 1) + 1];
-				n2 = geom[3 * (first + i + 1) + 2];
+	// The next triangle is fetched while the current one is tested (PREFETCH = 1). Deeper, grouped
+	// prefetch (2-8 triangles ahead, two register buffers) was measured and is SLOWER on MI355X
+	// (704 -> 630/594/524/406 Mrays/s for groups of 2/3/4/6): the registers it takes cost more
+	// occupancy than the extra loads in flight buy. No prefetch at 8 waves/SIMD is slower too (485).
+	if (PREFETCH) {
+		if (count > 0) {
+			float4 g0 = geom[3 * first + 0], g1 = geom[3 * first + 1], g2 = geom[3 * first + 2];
+			for (int i = 0; i < count; ++i) {
+				float4 n0 = g0, n1 = g1, n2 = g2;
+				if (i + 1 < count) {
+					n0 = geom[3 * (first + i + 1) + 0];
+					n1 = geom[3 * (first + i + 1) + 1];
+					n2 = geom[3 * (first + i + 1) + 2];
+				}
+				if (FLAGS & PT_F_STATS) steps++;
+				float t, u, v;
+				if (tri_test(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
+					ts.intersects = true;
+					if (t < ts.tmin) { ts.tmin = t; ts.tri = first + i; ts.bu = u; ts.bv = v; }
+				}
+				g0 = n0; g1 = n1; g2 = n2;
 			}
+		}
+	} else {
+		for (int i = 0; i < count; ++i) {
+			const float4 g0 = geom[3 * (first + i) + 0], g1 = geom[3 * (first + i) + 1], g2 = geom[3 * (first + i) + 2];
 			if (FLAGS & PT_F_STATS) steps++;
 			float t, u, v;
 			if (tri_test(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
 				ts.intersects = true;
-				if (t < ts.tmin) {
-					ts.tmin = t;
-					ts.tri = first + i;
-					ts.bu = u;
-					ts.bv = v;
-				}
+				if (t < ts.tmin) { ts.tmin = t; ts.tri = first + i; ts.bu = u; ts.bv = v; }
 			}
-			g0 = n0; g1 = n1; g2 = n2;
 		}
 	}
 	// pop

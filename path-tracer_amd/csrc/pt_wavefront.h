@@ -68,7 +68,7 @@ PT_DEV int wave_append(int* counter, bool pred) {
 }
 
 PT_DEV void stats_flush(PtxStats* stats, const TraceCounters& cnt, uint64_t rays, uint64_t paths, uint64_t hm, uint64_t hs,
-                        uint64_t ht, uint64_t act, uint64_t tot, bool detailed) {
+                        uint64_t ht, uint64_t act, uint64_t tot, bool detailed, uint64_t trav_rays = 0, bool is_traverse = false) {
 	const int lane = threadIdx.x & 63;
 	rays = wave_sum_u64(rays);
 	paths = wave_sum_u64(paths);
@@ -78,11 +78,13 @@ PT_DEV void stats_flush(PtxStats* stats, const TraceCounters& cnt, uint64_t rays
 		c_sphere = wave_sum_u64(cnt.n_sphere); c_leaf = wave_sum_u64(cnt.n_leaf);
 		hm = wave_sum_u64(hm); hs = wave_sum_u64(hs); ht = wave_sum_u64(ht);
 		act = wave_sum_u64(act); tot = wave_sum_u64(tot);
+		trav_rays = wave_sum_u64(trav_rays);
 	}
 	if (lane == 0) {
 		if (rays) atomicAdd((unsigned long long*)&stats->rays, (unsigned long long)rays);
 		if (paths) atomicAdd((unsigned long long*)&stats->paths, (unsigned long long)paths);
 		if (detailed) {
+			if (trav_rays) atomicAdd((unsigned long long*)&stats->trav_rays, (unsigned long long)trav_rays);
 			atomicAdd((unsigned long long*)&stats->n_inner, (unsigned long long)c_inner);
 			atomicAdd((unsigned long long*)&stats->n_box, (unsigned long long)c_box);
 			atomicAdd((unsigned long long*)&stats->n_tri, (unsigned long long)c_tri);
@@ -93,6 +95,12 @@ PT_DEV void stats_flush(PtxStats* stats, const TraceCounters& cnt, uint64_t rays
 			atomicAdd((unsigned long long*)&stats->hit_textured, (unsigned long long)ht);
 			atomicAdd((unsigned long long*)&stats->lane_steps_active, (unsigned long long)act);
 			atomicAdd((unsigned long long*)&stats->lane_steps_total, (unsigned long long)tot);
+			if (is_traverse) {
+				atomicAdd((unsigned long long*)&stats->trav_inner, (unsigned long long)c_inner);
+				atomicAdd((unsigned long long*)&stats->trav_box, (unsigned long long)c_box);
+				atomicAdd((unsigned long long*)&stats->trav_tri, (unsigned long long)c_tri);
+				atomicAdd((unsigned long long*)&stats->trav_leaf, (unsigned long long)c_leaf);
+			}
 		}
 	}
 }
@@ -310,8 +318,8 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCa
 // the top of the next traversal step, so a long ray no longer holds 63 finished lanes hostage
 // (measured before: 29 % useful lanes in this kernel). Chunks are large (queue / resident waves,
 // ~1000+ rays), which evens out the total work per wave.
-template <int FLAGS>
-__global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
+template <int FLAGS, int PREFETCH, int OCC>
+__global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
 	extern __shared__ int lds_stack[];
 	const int tid = threadIdx.x, lane = tid & 63;
 	int* stack = lds_stack + tid;
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(DevScene sc, WfPa
 	const int n = WF_CNT(wp, wp.bounce, 1 + slot_index);
 	const int* __restrict__ queue = wp.queue[slot_index];
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
-	uint64_t act = 0, tot = 0;
+	uint64_t act = 0, tot = 0, n_taken = 0;
 
 	const long long nw = (long long)gridDim.x * (PT_BLOCK / 64);
 	const long long gw = (long long)blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
@@ -339,6 +347,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(DevScene sc, WfPa
 		if (idle != 0ull && next < hi) {
 			const int mine = next + (int)__popcll(idle & ((1ull << lane) - 1ull));
 			if (!active && mine < hi) {
+				if (FLAGS & PT_F_STATS) n_taken++;
 				path = queue[mine];
 				const float4 a0 = wp.s0[path], a1 = wp.s1[path];
 				init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(DevScene sc, WfPa
 		uint32_t steps = 0;
 		if (active) {
 			float dbg = 1.0f;
-			const bool finished = traverse_step<FLAGS>(sc, ob, obj_index, ray, stack, PT_BLOCK, ts, cnt, dbg, steps);
+			const bool finished = traverse_step<FLAGS, PREFETCH>(sc, ob, obj_index, ray, stack, PT_BLOCK, ts, cnt, dbg, steps);
 			if (finished) {
 				if (ts.intersects && ts.tri >= 0) {
 					const f3 p = ray.o + ts.tmin * ray.d;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_traverse_kernel(DevScene sc, WfPa
 			if (lane == 0) tot += 64ull * mx;
 		}
 	}
-	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0);
+	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
 }
 
 // reference: src/pathtracing.cu:151 acc_image[index] += make_float4(radiance), once per iteration, in order

@@ -30,6 +30,10 @@ static int fail(int code, const char* fmt, ...) {
 			return fail(PTX_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
 	} while (0)
 
+struct PtxCtx;
+static void prof_mark(PtxCtx* c, int cls);
+static void prof_clear(PtxCtx* c);
+
 struct PtxCtx {
 	int device;
 	hipStream_t stream;
@@ -48,6 +52,9 @@ struct PtxCtx {
 	int wf_queues;
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
+	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
+	bool profiling;
+	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
 };
 
 struct PtxScene {
@@ -111,6 +118,11 @@ extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 	if (c->wf_batch > 64) c->wf_batch = 64;
 	const char* em = getenv("PTX_MEGAKERNEL");
 	c->force_megakernel = em && atoi(em) != 0;
+	const char* ev = getenv("PTX_TRAV_VARIANT");
+	c->trav_variant = ev ? atoi(ev) : 0;
+	const char* ebk = getenv("PTX_TRAV_BLOCKS");
+	c->trav_blocks_per_cu = ebk ? atoi(ebk) : 16;
+	if (c->trav_blocks_per_cu < 1) c->trav_blocks_per_cu = 1;
 	*out = c;
 	return PTX_OK;
 }
@@ -157,6 +169,9 @@ extern "C" int ptx_ctx_destroy(PtxCtx* ctx) {
 	hipStreamSynchronize(ctx->stream);
 	ptx_render_cleanup(ctx);
 	wf_free(ctx);
+	prof_clear(ctx);
+	delete ctx->prof_ev[0];
+	delete ctx->prof_ev[1];
 	if (ctx->d_stats) hipFree(ctx->d_stats);
 	if (ctx->d_pbo) hipFree(ctx->d_pbo);
 	hipEventDestroy(ctx->ev0);
@@ -503,18 +518,31 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 			wp.is_last = bounce == maxb ? 1 : 0;
 			size_t blocks = ((size_t)wp.n_total + WF_ROUNDS * PT_BLOCK - 1) / (WF_ROUNDS * PT_BLOCK);
 			if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
+			prof_mark(ctx, 1);
 			if (collect_stats)
 				hipLaunchKernelGGL(wf_segment_kernel<PT_F_STATS>, dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
 			else
 				hipLaunchKernelGGL(wf_segment_kernel<0>, dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+			prof_mark(ctx, 1);
 			HIP_TRY(hipGetLastError());
 			if (wp.is_last) break;
 			for (int k = 0; k < scene->num_big; ++k) {
-				const size_t tb = (size_t)cus * 8; // persistent waves, each owns queue/waves entries
-				if (collect_stats)
-					hipLaunchKernelGGL(wf_traverse_kernel<PT_F_STATS>, dim3((unsigned)tb), dim3(PT_BLOCK), stack_lds_bytes(scene), ctx->stream, scene->dev, wp, scene->big_object[k], k);
-				else
-					hipLaunchKernelGGL(wf_traverse_kernel<0>, dim3((unsigned)tb), dim3(PT_BLOCK), stack_lds_bytes(scene), ctx->stream, scene->dev, wp, scene->big_object[k], k);
+				const size_t tb = (size_t)cus * (size_t)ctx->trav_blocks_per_cu; // persistent waves, each owns queue/waves entries
+				const size_t lds = stack_lds_bytes(scene);
+				const int obj = scene->big_object[k];
+				prof_mark(ctx, 0);
+#define TRAV(F, P, O) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
+				// <stats, next-triangle prefetch, min waves/SIMD the register allocator must allow>;
+				// measured best: prefetch on, 3 waves/SIMD bound (PTX_TRAV_VARIANT selects the others for A/B)
+				if (collect_stats) TRAV(PT_F_STATS, 1, 3);
+				else switch (ctx->trav_variant) {
+					case 1: TRAV(0, 0, 8); break;
+					case 2: TRAV(0, 1, 6); break;
+					case 3: TRAV(0, 1, 4); break;
+					default: TRAV(0, 1, 3); break;
+				}
+#undef TRAV
+				prof_mark(ctx, 0);
 				HIP_TRY(hipGetLastError());
 			}
 		}
@@ -522,6 +550,70 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		                   ctx->accum, (const float4*)wp.rad, (int)npix, b);
 		HIP_TRY(hipGetLastError());
 	}
+	return PTX_OK;
+}
+
+extern "C" int ptx_wavefront_counts(PtxCtx* ctx, int max_bounces, int32_t* live_out, int32_t* queued_out) {
+	if (!ctx || !live_out || !queued_out || max_bounces < 0 || max_bounces > PT_WF_MAX_BOUNCES) return fail(PTX_E_INVALID, "ptx_wavefront_counts: bad arguments");
+	if (!ctx->wf.counters) return fail(PTX_E_STATE, "ptx_wavefront_counts: no wavefront pass has run");
+	HIP_TRY(hipSetDevice(ctx->device));
+	std::vector<int> h((size_t)(max_bounces + 1) * (1 + PT_MAX_BIG));
+	HIP_TRY(hipMemcpyAsync(h.data(), ctx->wf.counters, h.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	for (int b = 0; b <= max_bounces; ++b) {
+		live_out[b] = h[(size_t)b * (1 + PT_MAX_BIG)];
+		int q = 0;
+		for (int k = 0; k < PT_MAX_BIG; ++k) q += h[(size_t)b * (1 + PT_MAX_BIG) + 1 + k];
+		queued_out[b] = q;
+	}
+	return PTX_OK;
+}
+
+static void prof_mark(PtxCtx* c, int cls) {
+	if (!c->profiling) return;
+	if (!c->prof_ev[cls]) c->prof_ev[cls] = new std::vector<hipEvent_t>();
+	hipEvent_t e;
+	if (hipEventCreate(&e) != hipSuccess) return;
+	hipEventRecord(e, c->stream);
+	c->prof_ev[cls]->push_back(e);
+}
+
+static void prof_clear(PtxCtx* c) {
+	for (int k = 0; k < 2; ++k)
+		if (c->prof_ev[k]) {
+			for (size_t i = 0; i < c->prof_ev[k]->size(); ++i) hipEventDestroy((*c->prof_ev[k])[i]);
+			c->prof_ev[k]->clear();
+		}
+}
+
+extern "C" int ptx_profile_enable(PtxCtx* ctx, int enable) {
+	if (!ctx) return fail(PTX_E_INVALID, "ptx_profile_enable: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	prof_clear(ctx);
+	ctx->profiling = enable != 0;
+	return PTX_OK;
+}
+
+extern "C" int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches, float* segment_ms, int32_t* segment_launches) {
+	if (!ctx || !traverse_ms || !traverse_launches || !segment_ms || !segment_launches) return fail(PTX_E_INVALID, "ptx_profile_get: NULL argument");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	float* ms[2] = {traverse_ms, segment_ms};
+	int32_t* cnt[2] = {traverse_launches, segment_launches};
+	for (int k = 0; k < 2; ++k) {
+		*ms[k] = 0.0f;
+		*cnt[k] = 0;
+		if (!ctx->prof_ev[k]) continue;
+		const std::vector<hipEvent_t>& v = *ctx->prof_ev[k];
+		for (size_t i = 0; i + 1 < v.size(); i += 2) {
+			float e = 0.0f;
+			HIP_TRY(hipEventElapsedTime(&e, v[i], v[i + 1]));
+			*ms[k] += e;
+			(*cnt[k])++;
+		}
+	}
+	prof_clear(ctx);
 	return PTX_OK;
 }
 

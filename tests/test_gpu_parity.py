@@ -104,7 +104,8 @@ def test_radiance_and_accumulation_bit_exact(pt, orc, ctx, name, tex):
     # one launch of 8 samples == 8 launches of 1 sample == reference schedule
     acc_g1, _ = gpuops.render(ctx, scene, cam, 0, 8, 42, batch=1)
     assert np.array_equal(acc_g.view(np.uint32), acc_g1.view(np.uint32))
-    for k in ("rays", "paths", "n_inner", "n_box", "n_tri", "n_sphere", "n_leaf", "hit_mesh", "hit_sphere", "hit_textured"):
+    for k in ("rays", "paths", "n_inner", "n_box", "n_tri", "n_sphere", "n_leaf", "hit_mesh", "hit_sphere", "hit_textured",
+              "trav_rays", "trav_inner", "trav_box", "trav_tri", "trav_leaf"):
         assert getattr(st_o, k) == getattr(st_g, k), f"{name}: counter {k}: oracle {getattr(st_o, k)} gpu {getattr(st_g, k)}"
     assert acc_o[:, :3].max() > 0
 
