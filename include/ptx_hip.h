@@ -141,6 +141,11 @@ typedef struct PtxStats {
 	/* idem, restricted to multi-node meshes (what wf_traverse_kernel does): rays entering their root box,
 	 * inner-node steps, box tests below the root, triangle tests, leaves */
 	uint64_t trav_rays, trav_inner, trav_box, trav_tri, trav_leaf;
+	/* kernel-tuning counters of the traversal kernels (stats variant; meaning may change between versions):
+	 * per-lane kernel: diag0 = lanes holding a ray, diag1 = 64 per wave step (lane occupancy of the waves);
+	 * cooperative kernel: diag0/diag1 = descending lanes / 64 per descent iteration, diag2/diag3 = lanes
+	 * testing a triangle / 64 per leaf pass */
+	uint64_t diag0, diag1, diag2, diag3;
 } PtxStats;
 
 /* BSDF known-answer entry (parity for surfaces.cuh). */
@@ -212,6 +217,13 @@ int ptx_wavefront_counts(PtxCtx* ctx, int max_bounces, int32_t* live_out, int32_
  * summed durations / launch counts since enabling and clears them. No reference counterpart. */
 int ptx_profile_enable(PtxCtx* ctx, int enable);
 int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches, float* segment_ms, int32_t* segment_launches);
+/* Scheduling knobs of the render path (no reference counterpart; results do not depend on them, the parity
+ * tests run the variants against each other): key = "trav_variant" (traversal kernel variant, see
+ * ptx_hip.hip), "trav_blocks" (persistent blocks per CU), "wf_batch" (samples per wavefront pass, 1..64),
+ * "megakernel" (1 = one-lane-per-pixel kernel instead of the wavefront pipeline). Defaults come from the
+ * environment (PTX_TRAV_VARIANT, PTX_TRAV_BLOCKS, PTX_WF_BATCH, PTX_MEGAKERNEL) at ptx_ctx_create.
+ * value < 0 restores that default. */
+int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value);
 /* HIP-event timer on the context's stream (for bench.py's roofline leg). */
 int ptx_timer_begin(PtxCtx* ctx);
 int ptx_timer_end(PtxCtx* ctx, float* elapsed_ms);

@@ -77,7 +77,8 @@ class PtxStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "paths", "n_inner", "n_box", "n_tri", "n_sphere", "n_leaf",
                                           "hit_mesh", "hit_sphere", "hit_textured",
                                           "lane_steps_active", "lane_steps_total",
-                                          "trav_rays", "trav_inner", "trav_box", "trav_tri", "trav_leaf")]
+                                          "trav_rays", "trav_inner", "trav_box", "trav_tri", "trav_leaf",
+                                          "diag0", "diag1", "diag2", "diag3")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -96,7 +97,7 @@ PTX_SYMBOLS = [
     "ptx_scene_upload", "ptx_scene_free", "ptx_scene_device_bytes", "ptx_render_init", "ptx_render_set_camera",
     "ptx_render_cleanup", "ptx_accum_clear", "ptx_render_samples", "ptx_render_sync", "ptx_accum_device_ptr",
     "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_stats_get", "ptx_stats_reset",
-    "ptx_wavefront_counts", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample",
+    "ptx_wavefront_counts", "ptx_ctx_tune", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample",
 ]
 
 _lib = None
@@ -140,6 +141,7 @@ def lib():
         L.ptx_stats_get.argtypes = [vp, C.POINTER(PtxStats)]
         L.ptx_stats_reset.argtypes = [vp]
         L.ptx_wavefront_counts.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.ptx_ctx_tune.argtypes = [vp, C.c_char_p, i32]
         L.ptx_profile_enable.argtypes = [vp, i32]
         L.ptx_profile_get.argtypes = [vp, fp, C.POINTER(C.c_int32), fp, C.POINTER(C.c_int32)]
         L.ptx_timer_begin.argtypes = [vp]

@@ -17,6 +17,9 @@
 //              contiguous runs and the reference's trg_idxs indirection disappears):
 //                g0 = (a.x, a.y, a.z, e1.x)  g1 = (e1.y, e1.z, e2.x, e2.y)
 //                g2 = (e2.z, int original_prim_id, int leaf_node_local_idx, 0)
+//   tri_soa    the same triangles in the same order as three float4 planes of num_tris entries
+//              (a.xyz|prim id), (e1.xyz|0), (e2.xyz|0): the cooperative traversal kernel tests 32
+//              consecutive triangles of a leaf with 32 lanes, so each plane read is one contiguous 512 B
 //   tri_shade  4 x float4 per triangle (64 B), same order, touched once per mesh hit:
 //                s0 = (na.xyz, ta.x) s1 = (nb.xyz, ta.y) s2 = (nc.xyz, tb.x)
 //                s3 = (tb.y, tc.x, tc.y, int material_global_idx)
@@ -52,11 +55,13 @@ struct DevScene {
 	const DevObject* objects;
 	const float4* nodes;
 	const float4* tri_geom;
+	const float4* tri_soa;  // the same triangles as three planes: a[], e1[], e2[] (float4 each, .w of plane 0 = prim id)
 	const float4* tri_shade;
 	const float4* materials;
 	const DevTexture* textures;
 	int32_t num_objects;
 	int32_t stack_entries;  // LDS traversal-stack slots per lane (>= deepest tree level, >= 1)
+	int32_t num_tris;       // triangles in tri_geom / per plane of tri_soa
 };
 
 struct DevCamera {

@@ -52,6 +52,27 @@ struct WfParams {
 };
 
 #define WF_CNT(wp, b, k) ((wp).counters[(b) * (1 + PT_MAX_BIG) + (k)])
+// dynamic work distribution of the traversal kernels: next unclaimed queue entry per (bounce, queue)
+#define WF_CUR(wp, b, k) ((wp).counters[(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) + (b) * (1 + PT_MAX_BIG) + (k)])
+
+// Queue feed of a persistent traversal wave. A wave claims CHUNK consecutive queue entries at a time
+// with one atomic (wave-uniform state: next/hi/exhausted), so every wave keeps all its lanes fed until
+// the whole queue is drained — with a static split a wave owns only ~2 rays per lane and spends most
+// of its life draining a tail of long rays with few lanes. CHUNK is large enough that the atomics
+// (queue / CHUNK per launch, ~10^4) stay far below the rate at which one address serialises.
+struct WaveFeed {
+	int next, hi;
+	bool exhausted;
+};
+
+PT_DEV void feed_claim(WaveFeed& f, int* cursor, int n, int chunk) {
+	int base = 0;
+	if ((threadIdx.x & 63) == 0) base = atomicAdd(cursor, chunk);
+	base = __builtin_amdgcn_readfirstlane(base);
+	f.next = base;
+	f.hi = base + chunk < n ? base + chunk : n;
+	if (base >= n) { f.exhausted = true; f.next = f.hi = 0; }
+}
 
 // Stream compaction inside a wave: returns the slot of this lane in the list `counter` counts, or -1.
 // Must be reached by whole waves (callers keep their loops wave-uniform).
@@ -102,6 +123,16 @@ PT_DEV void stats_flush(PtxStats* stats, const TraceCounters& cnt, uint64_t rays
 				atomicAdd((unsigned long long*)&stats->trav_leaf, (unsigned long long)c_leaf);
 			}
 		}
+	}
+}
+
+PT_DEV void diag_flush(PtxStats* stats, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3) {
+	d0 = wave_sum_u64(d0); d1 = wave_sum_u64(d1); d2 = wave_sum_u64(d2); d3 = wave_sum_u64(d3);
+	if ((threadIdx.x & 63) == 0) {
+		atomicAdd((unsigned long long*)&stats->diag0, (unsigned long long)d0);
+		atomicAdd((unsigned long long*)&stats->diag1, (unsigned long long)d1);
+		atomicAdd((unsigned long long*)&stats->diag2, (unsigned long long)d2);
+		atomicAdd((unsigned long long*)&stats->diag3, (unsigned long long)d3);
 	}
 }
 
@@ -318,7 +349,7 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCa
 // the top of the next traversal step, so a long ray no longer holds 63 finished lanes hostage
 // (measured before: 29 % useful lanes in this kernel). Chunks are large (queue / resident waves,
 // ~1000+ rays), which evens out the total work per wave.
-template <int FLAGS, int PREFETCH, int OCC>
+template <int FLAGS, int PREFETCH, int OCC, int CHUNK>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
 	extern __shared__ int lds_stack[];
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -327,12 +358,20 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 	const int n = WF_CNT(wp, wp.bounce, 1 + slot_index);
 	const int* __restrict__ queue = wp.queue[slot_index];
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
-	uint64_t act = 0, tot = 0, n_taken = 0;
+	uint64_t act = 0, tot = 0, n_taken = 0, dg0 = 0, dg1 = 0, dg2 = 0, dg3 = 0;
 
-	const long long nw = (long long)gridDim.x * (PT_BLOCK / 64);
-	const long long gw = (long long)blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
-	int next = (int)(((long long)n * gw) / nw);          // wave-uniform cursor into this wave's chunk
-	const int hi = (int)(((long long)n * (gw + 1)) / nw);
+	WaveFeed feed;
+	feed.exhausted = CHUNK == 0;
+	if (CHUNK == 0) {
+		// static split: wave w owns queue[n*w/W, n*(w+1)/W)
+		const long long nw = (long long)gridDim.x * (PT_BLOCK / 64);
+		const long long gw = (long long)blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
+		feed.next = (int)(((long long)n * gw) / nw);
+		feed.hi = (int)(((long long)n * (gw + 1)) / nw);
+	} else {
+		feed.next = feed.hi = 0;
+	}
+	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
 
 	bool active = false;
 	int path = 0;
@@ -343,10 +382,16 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 
 	for (;;) {
 		// ---- refill idle lanes from the wave's chunk ----
-		const unsigned long long idle = __ballot(!active);
-		if (idle != 0ull && next < hi) {
-			const int mine = next + (int)__popcll(idle & ((1ull << lane) - 1ull));
-			if (!active && mine < hi) {
+		for (int attempt = 0; attempt < 2; ++attempt) {
+			const unsigned long long idle = __ballot(!active);
+			if (idle == 0ull) break;
+			if (feed.next >= feed.hi) {
+				if (feed.exhausted) break;
+				feed_claim(feed, cursor, n, CHUNK);
+				if (feed.exhausted) break;
+			}
+			const int mine = feed.next + (int)__popcll(idle & ((1ull << lane) - 1ull));
+			if (!active && mine < feed.hi) {
 				if (FLAGS & PT_F_STATS) n_taken++;
 				path = queue[mine];
 				const float4 a0 = wp.s0[path], a1 = wp.s1[path];
@@ -355,9 +400,10 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 				trav_begin(ts, ob);
 				active = true;
 			}
-			next += (int)__popcll(idle);
+			feed.next += (int)__popcll(idle);
 		}
 		if (__ballot(active) == 0ull) break;
+		if (FLAGS & PT_F_STATS) { dg0 += active ? 1 : 0; if (lane == 0) dg1 += 64; }
 
 		uint32_t steps = 0;
 		if (active) {
@@ -392,6 +438,218 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 		}
 	}
 	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
+	if (FLAGS & PT_F_STATS) diag_flush(wp.stats, dg0, dg1, dg2, dg3);
+}
+
+// Cooperative variant of the traversal kernel: the DESCENT stays one ray per lane, the LEAVES are
+// tested by the wave together.
+//
+// Why: a KD leaf of the reference's builder holds 17..33 triangles (children only when the left half
+// is > 16, src/KDTree.cpp:96) and a ray visits ~12 leaves, so ~300 triangle tests per traversal
+// against ~50 inner nodes. One ray per lane walks those triangles serially: 64 lanes fetch 64
+// unrelated 48-B records per step (the vector memory path is 72 % busy, profiles/r01_wavefront_*)
+// and only a quarter of the lanes of a VALU instruction do useful work. Here every lane that holds
+// a leaf hands it to the wave: two leaves per step, one per 32-lane half; the owner's ray is
+// broadcast, lane i tests triangle i of the run (three contiguous 512-B plane reads), and the hits
+// are folded back into the owner's state IN TRIANGLE ORDER with the reference's strict '<', so the
+// result is exactly what the serial loop gives (first triangle wins ties).
+//
+// Round structure (wave-uniform control flow throughout):
+//   refill idle lanes from the wave's queue chunk -> all lanes descend until each holds a leaf or is
+//   done -> leaves are processed two at a time -> owners pop their stacks.
+template <int FLAGS, int OCC, int CHUNK>
+__global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
+	extern __shared__ int lds_stack[];
+	const int tid = threadIdx.x, lane = tid & 63, sub = lane & 31;
+	const bool upper = lane >= 32;
+	int* stack = lds_stack + tid;
+	const DevObject& ob = sc.objects[obj_index];
+	const int n = WF_CNT(wp, wp.bounce, 1 + slot_index);
+	const int* __restrict__ queue = wp.queue[slot_index];
+	const float4* __restrict__ nodes = sc.nodes;
+	const float4* __restrict__ pa = sc.tri_soa;
+	const float4* __restrict__ pe1 = sc.tri_soa + sc.num_tris;
+	const float4* __restrict__ pe2 = sc.tri_soa + 2 * (size_t)sc.num_tris;
+	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
+	uint64_t act = 0, tot = 0, n_taken = 0, dg0 = 0, dg1 = 0, dg2 = 0, dg3 = 0;
+
+	WaveFeed feed;
+	feed.exhausted = CHUNK == 0;
+	if (CHUNK == 0) {
+		// static split: wave w owns queue[n*w/W, n*(w+1)/W)
+		const long long nw = (long long)gridDim.x * (PT_BLOCK / 64);
+		const long long gw = (long long)blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
+		feed.next = (int)(((long long)n * gw) / nw);
+		feed.hi = (int)(((long long)n * (gw + 1)) / nw);
+	} else {
+		feed.next = feed.hi = 0;
+	}
+	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
+
+	enum { IDLE = 0, DESCEND = 1, LEAF = 2 };
+	int state = IDLE;
+	int path = 0, leaf_first = 0, leaf_count = 0;
+	float cur_d = 0.0f;
+	Ray ray;
+	TravState ts;
+	ts.curr = -1; ts.sp = 0; ts.tri = -1; ts.tmin = 0.0f; ts.bu = ts.bv = 0.0f; ts.intersects = false;
+	init_ray(ray, mk3(0.0f), mk3(1.0f));
+
+	// the traversal of this lane's ray is over: merge into the path's closest-hit record
+	auto commit = [&]() {
+		if (ts.intersects && ts.tri >= 0) {
+			const f3 p = ray.o + ts.tmin * ray.d;
+			const float d = length3(p - ray.o);
+			const int cur_obj = __float_as_int(wp.s2[path].w);
+			if (d < cur_d || (d == cur_d && cur_obj >= 0 && obj_index < cur_obj)) {
+				wp.s0[path].w = d;
+				wp.s1[path].w = ts.tmin;
+				wp.s2[path].w = __int_as_float(obj_index);
+				wp.s3[path] = make_float4(__int_as_float(ts.tri), ts.bu, ts.bv, 0.0f);
+			}
+		}
+		state = IDLE;
+	};
+
+	for (;;) {
+		// ---- refill idle lanes from the wave's chunk ----
+		for (int attempt = 0; attempt < 2; ++attempt) {
+			const unsigned long long idle = __ballot(state == IDLE);
+			if (idle == 0ull) break;
+			if (feed.next >= feed.hi) {
+				if (feed.exhausted) break;
+				feed_claim(feed, cursor, n, CHUNK);
+				if (feed.exhausted) break;
+			}
+			const int mine = feed.next + (int)__popcll(idle & ((1ull << lane) - 1ull));
+			if (state == IDLE && mine < feed.hi) {
+				if (FLAGS & PT_F_STATS) n_taken++;
+				path = queue[mine];
+				const float4 a0 = wp.s0[path], a1 = wp.s1[path];
+				init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
+				cur_d = a0.w;
+				trav_begin(ts, ob);
+				state = DESCEND;
+			}
+			feed.next += (int)__popcll(idle);
+		}
+		if (__ballot(state != IDLE) == 0ull) break;
+
+		// ---- descent: every lane walks inner nodes until it holds a leaf or its traversal ends ----
+		while (__ballot(state == DESCEND) != 0ull) {
+			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; dg1 += 64; } }
+			if (state == DESCEND) {
+				if (FLAGS & PT_F_STATS) { act++; dg0++; }
+				const int curr = ts.curr;
+				const float4 q3 = nodes[4 * curr + 3];
+				const float4 q0 = nodes[4 * curr + 0];
+				const float4 q1 = nodes[4 * curr + 1];
+				const float4 q2 = nodes[4 * curr + 2];
+				const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+				if (left == -1 && right == -1) {
+					leaf_first = __float_as_int(q3.z);
+					leaf_count = __float_as_int(q3.w);
+					if (FLAGS & PT_F_STATS) {
+						cnt.n_leaf++;
+						cnt.n_tri += (uint32_t)leaf_count;
+						fnv_word(cnt.leaf_hash, (uint32_t)obj_index);
+						fnv_word(cnt.leaf_hash, (uint32_t)(curr - ob.first_node));
+					}
+					state = LEAF;
+				} else {
+					if (FLAGS & PT_F_STATS) cnt.n_inner++;
+					float left_dist = __builtin_huge_valf(), right_dist = __builtin_huge_valf();
+					bool left_res = false, right_res = false;
+					if (left != -1) {
+						if (FLAGS & PT_F_STATS) cnt.n_box++;
+						left_res = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ray, left_dist) && (left_dist < ts.tmin);
+					}
+					if (right != -1) {
+						if (FLAGS & PT_F_STATS) cnt.n_box++;
+						right_res = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ray, right_dist) && (right_dist < ts.tmin);
+					}
+					if (left_res && right_res) {
+						int further = right, nxt = right;
+						if (left_dist > right_dist) further = left; else nxt = left;
+						stack[ts.sp * PT_BLOCK] = further;
+						++ts.sp;
+						ts.curr = nxt;
+					} else if (left_res) {
+						ts.curr = left;
+					} else if (right_res) {
+						ts.curr = right;
+					} else if (ts.sp == 0) {
+						commit();
+					} else {
+						--ts.sp;
+						ts.curr = stack[ts.sp * PT_BLOCK];
+					}
+				}
+			}
+		}
+
+		// ---- leaves: two owners per step, one per half-wave ----
+		unsigned long long m = __ballot(state == LEAF);
+		while (m != 0ull) {
+			const int l0 = (int)__ffsll((long long)m) - 1;
+			m &= m - 1ull;
+			int l1 = -1;
+			if (m != 0ull) { l1 = (int)__ffsll((long long)m) - 1; m &= m - 1ull; }
+			const bool on = !upper || l1 >= 0;
+			const int src = (upper && l1 >= 0) ? l1 : l0;
+			const float ox = __shfl(ray.o.x, src, 64), oy = __shfl(ray.o.y, src, 64), oz = __shfl(ray.o.z, src, 64);
+			const float dx = __shfl(ray.d.x, src, 64), dy = __shfl(ray.d.y, src, 64), dz = __shfl(ray.d.z, src, 64);
+			const int first = __shfl(leaf_first, src, 64);
+			const int count_src = __shfl(leaf_count, src, 64); // every lane takes part: the source may sit in the other half
+			const int count = on ? count_src : 0;
+			const int c0 = __builtin_amdgcn_readlane(leaf_count, l0);
+			const int c1 = l1 >= 0 ? __builtin_amdgcn_readlane(leaf_count, l1) : 0;
+			const int cmax = c0 > c1 ? c0 : c1;
+			Ray br;
+			br.o = mk3(ox, oy, oz);
+			br.d = mk3(dx, dy, dz);
+			for (int base = 0; base < cmax; base += 32) {
+				const int i = base + sub;
+				bool hit = false;
+				float t = 0.0f, u = 0.0f, v = 0.0f;
+				if (i < count) {
+					const float4 a = pa[first + i], e1 = pe1[first + i], e2 = pe2[first + i];
+					hit = tri_test(br, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t, u, v);
+					if (FLAGS & PT_F_STATS) { act++; dg2++; }
+				}
+				if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; dg3 += 64; } }
+				const unsigned long long hm = __ballot(hit);
+				uint32_t h0 = (uint32_t)hm, h1 = (uint32_t)(hm >> 32);
+				// fold the hits into the owners in triangle order (the serial loop's order)
+				while ((h0 | h1) != 0u) {
+					const int w0 = h0 ? (int)__ffs((int)h0) - 1 : 0;
+					const int w1 = h1 ? 32 + (int)__ffs((int)h1) - 1 : 32;
+					const bool second = lane == l1;
+					const int w = second ? w1 : w0;
+					const float tt = __shfl(t, w, 64), uu = __shfl(u, w, 64), vv = __shfl(v, w, 64);
+					const bool mine = (lane == l0 && h0 != 0u) || (second && h1 != 0u);
+					if (mine) {
+						ts.intersects = true;
+						if (tt < ts.tmin) { ts.tmin = tt; ts.tri = leaf_first + base + (w & 31); ts.bu = uu; ts.bv = vv; }
+					}
+					h0 &= h0 - 1u;
+					h1 &= h1 - 1u;
+				}
+			}
+		}
+
+		// ---- owners pop ----
+		if (state == LEAF) {
+			if (ts.sp == 0) commit();
+			else {
+				--ts.sp;
+				ts.curr = stack[ts.sp * PT_BLOCK];
+				state = DESCEND;
+			}
+		}
+	}
+	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
+	if (FLAGS & PT_F_STATS) diag_flush(wp.stats, dg0, dg1, dg2, dg3);
 }
 
 // reference: src/pathtracing.cu:151 acc_image[index] += make_float4(radiance), once per iteration, in order

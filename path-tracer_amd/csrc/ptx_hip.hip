@@ -95,6 +95,36 @@ extern "C" int ptx_device_info(int device, char* name, int name_len, int* comput
 	return PTX_OK;
 }
 
+static int env_int(const char* name, int dflt) {
+	const char* e = getenv(name);
+	return e ? atoi(e) : dflt;
+}
+
+static void tune_defaults(PtxCtx* c) {
+	c->wf_batch = env_int("PTX_WF_BATCH", 8);
+	if (c->wf_batch < 1) c->wf_batch = 1;
+	if (c->wf_batch > 64) c->wf_batch = 64;
+	c->force_megakernel = env_int("PTX_MEGAKERNEL", 0) != 0;
+	c->trav_variant = env_int("PTX_TRAV_VARIANT", 0);
+	c->trav_blocks_per_cu = env_int("PTX_TRAV_BLOCKS", 16);
+	if (c->trav_blocks_per_cu < 1) c->trav_blocks_per_cu = 1;
+}
+
+extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
+	if (!ctx || !key) return fail(PTX_E_INVALID, "ptx_ctx_tune: NULL argument");
+	PtxCtx saved = *ctx;
+	tune_defaults(ctx);
+	const int d_batch = ctx->wf_batch, d_var = ctx->trav_variant, d_blocks = ctx->trav_blocks_per_cu;
+	const bool d_mega = ctx->force_megakernel;
+	*ctx = saved;
+	if (!strcmp(key, "trav_variant")) ctx->trav_variant = value < 0 ? d_var : value;
+	else if (!strcmp(key, "trav_blocks")) ctx->trav_blocks_per_cu = value < 0 ? d_blocks : (value < 1 ? 1 : (value > 64 ? 64 : value));
+	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d_batch : (value < 1 ? 1 : (value > 64 ? 64 : value));
+	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d_mega : value != 0;
+	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
+	return PTX_OK;
+}
+
 extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 	if (!out) return fail(PTX_E_INVALID, "ptx_ctx_create: out is NULL");
 	*out = NULL;
@@ -112,17 +142,7 @@ extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 	hipMemsetAsync(c->d_stats, 0, sizeof(PtxStats), c->stream);
 	hipEventCreate(&c->ev0);
 	hipEventCreate(&c->ev1);
-	const char* eb = getenv("PTX_WF_BATCH");
-	c->wf_batch = eb ? atoi(eb) : 8;
-	if (c->wf_batch < 1) c->wf_batch = 1;
-	if (c->wf_batch > 64) c->wf_batch = 64;
-	const char* em = getenv("PTX_MEGAKERNEL");
-	c->force_megakernel = em && atoi(em) != 0;
-	const char* ev = getenv("PTX_TRAV_VARIANT");
-	c->trav_variant = ev ? atoi(ev) : 0;
-	const char* ebk = getenv("PTX_TRAV_BLOCKS");
-	c->trav_blocks_per_cu = ebk ? atoi(ebk) : 16;
-	if (c->trav_blocks_per_cu < 1) c->trav_blocks_per_cu = 1;
+	tune_defaults(c);
 	*out = c;
 	return PTX_OK;
 }
@@ -156,7 +176,7 @@ static int wf_ensure(PtxCtx* c, size_t paths, size_t rad, int queues) {
 	HIP_TRY(hipMalloc((void**)&c->wf.live[0], paths * sizeof(int)));
 	HIP_TRY(hipMalloc((void**)&c->wf.live[1], paths * sizeof(int)));
 	for (int k = 0; k < queues; ++k) HIP_TRY(hipMalloc((void**)&c->wf.queue[k], paths * sizeof(int)));
-	HIP_TRY(hipMalloc((void**)&c->wf.counters, (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) * sizeof(int)));
+	HIP_TRY(hipMalloc((void**)&c->wf.counters, 2 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) * sizeof(int))); // counts + traversal cursors
 	c->wf_paths = paths;
 	c->wf_rad = rad;
 	c->wf_queues = queues;
@@ -352,6 +372,18 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	UP(objs, objects)
 	UP(nodes, nodes)
 	UP(geom, tri_geom)
+	{
+		const size_t nt = geom.size() / 3;
+		std::vector<float4> soa(nt * 3);
+		for (size_t i = 0; i < nt; ++i) {
+			const float4 g0 = geom[3 * i], g1 = geom[3 * i + 1], g2 = geom[3 * i + 2];
+			soa[i] = make_float4(g0.x, g0.y, g0.z, g2.y);
+			soa[nt + i] = make_float4(g0.w, g1.x, g1.y, 0.0f);
+			soa[2 * nt + i] = make_float4(g1.z, g1.w, g2.x, 0.0f);
+		}
+		UP(soa, tri_soa)
+		s->dev.num_tris = (int)nt;
+	}
 	UP(shade, tri_shade)
 	UP(mats, materials)
 #undef UP
@@ -512,7 +544,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		wp.n_total = (int)(npt * (size_t)b);
 		wp.k0 = k0; wp.k1 = k1;
 		wp.num_big = scene->num_big;
-		HIP_TRY(hipMemsetAsync(wp.counters, 0, (size_t)(maxb + 1) * (1 + PT_MAX_BIG) * sizeof(int), ctx->stream));
+		HIP_TRY(hipMemsetAsync(wp.counters, 0, 2 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) * sizeof(int), ctx->stream));
 		for (int bounce = 0; bounce <= maxb; ++bounce) {
 			wp.bounce = bounce;
 			wp.is_last = bounce == maxb ? 1 : 0;
@@ -531,17 +563,26 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				const size_t lds = stack_lds_bytes(scene);
 				const int obj = scene->big_object[k];
 				prof_mark(ctx, 0);
-#define TRAV(F, P, O) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
-				// <stats, next-triangle prefetch, min waves/SIMD the register allocator must allow>;
-				// measured best: prefetch on, 3 waves/SIMD bound (PTX_TRAV_VARIANT selects the others for A/B)
-				if (collect_stats) TRAV(PT_F_STATS, 1, 3);
-				else switch (ctx->trav_variant) {
-					case 1: TRAV(0, 0, 8); break;
-					case 2: TRAV(0, 1, 6); break;
-					case 3: TRAV(0, 1, 4); break;
-					default: TRAV(0, 1, 3); break;
+#define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
+#define COOP(F, O, C) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
+				// <stats, next-triangle prefetch, min waves/SIMD the register allocator must allow, queue chunk>
+				// PTX_TRAV_VARIANT selects the alternatives for A/B runs (tools/sweep.sh)
+				if (collect_stats) {
+					if (ctx->trav_variant >= 10) COOP(PT_F_STATS, 4, 128); else TRAV(PT_F_STATS, 1, 3, 128);
+				} else switch (ctx->trav_variant) {
+					case 1: TRAV(0, 1, 3, 0); break;     // static split (round-1 first version)
+					case 2: TRAV(0, 1, 3, 64); break;
+					case 3: TRAV(0, 1, 3, 256); break;
+					case 4: TRAV(0, 1, 4, 128); break;
+					case 5: TRAV(0, 0, 8, 128); break;
+					case 10: COOP(0, 4, 128); break;
+					case 11: COOP(0, 6, 128); break;
+					case 12: COOP(0, 8, 128); break;
+					case 13: COOP(0, 8, 0); break;
+					default: TRAV(0, 1, 3, 128); break;
 				}
 #undef TRAV
+#undef COOP
 				prof_mark(ctx, 0);
 				HIP_TRY(hipGetLastError());
 			}

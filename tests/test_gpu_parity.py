@@ -134,3 +134,25 @@ def test_tonemap_matches_oracle(pt, orc, ctx):
     # powf differs by at most 1 ulp between libm and the device library: allow 1 LSB on truncation
     assert np.abs(out_g.astype(int) - out_o.astype(int)).max() <= 1
     assert (out_g[:, 3] == 0).all()
+
+
+def test_full_size_lamborghini_matches_oracle(pt, orc, ctx):
+    """The bench workload itself (1920x1080, ~400k triangles), 1 spp, every traversal variant: accumulation
+    buffer and work counters bit-identical to the oracle."""
+    desc, cam = pt.load_scene("lamborghini", width=1920, height=1080, textures=1)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 3, 1, 7, nthreads=16)
+    try:
+        for variant in (0, 1, 10):
+            pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", variant))
+            for stats in (True, False):
+                acc_g, st_g = gpuops.render(ctx, scene, cam, 3, 1, 7, stats=stats)
+                diff = np.nonzero((acc_o.view(np.uint32) != acc_g.view(np.uint32)).any(axis=1))[0]
+                assert len(diff) == 0, f"variant {variant} stats {stats}: {len(diff)} pixels differ, first {diff[:5]}"
+                keys = ("rays", "paths") if not stats else ("rays", "paths", "n_inner", "n_box", "n_tri", "n_sphere", "n_leaf", "hit_mesh", "hit_sphere",
+                                                            "hit_textured", "trav_rays", "trav_inner", "trav_box", "trav_tri", "trav_leaf")
+                for k in keys:
+                    assert getattr(st_o, k) == getattr(st_g, k), f"variant {variant}: counter {k}: oracle {getattr(st_o, k)} gpu {getattr(st_g, k)}"
+    finally:
+        pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", -1))
