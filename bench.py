@@ -11,7 +11,7 @@ every rank renders its own disjoint sample range per step (weak scaling, no data
 collective) and ONE all-reduce (RCCL) of the float accumulation buffers closes the timed region.
 
 Prints one JSON line (rank 0) with the contract fields plus
-  "roofline"      for the dominant kernel, wf_traverse_kernel (KD traversal + ray/triangle tests of
+  "roofline"      for the dominant kernel, wf_traverse_coop_kernel (KD traversal + ray/triangle tests of
                   the rays queued for a multi-node mesh): algorithmic bytes per launch (DESIGN.md
                   "bytes per traversal"; counters measured on the SAME samples by the counting
                   variant) / mean launch duration from HIP event pairs recorded around every launch
@@ -35,15 +35,16 @@ VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 
 
 def traverse_bytes_and_flops(st):
-    """Algorithmic bytes / flops of wf_traverse_kernel (DESIGN.md "bytes per traversal").
+    """Algorithmic bytes / flops of the traversal kernel: the traversal terms of SURVEY.md 8(d)'s
+    bytes_per_ray / flops_per_ray (DESIGN.md "Roofline").
 
-    per inner-node visit: both children's boxes (12 floats) + links/leaf range (4 ints) = 64 B
-    per triangle test:    a, e1, e2 (9 floats) + primitive id                          = 40 B
-    per queued ray:       queue entry 4 + origin/direction 24 + hit record read and write 16+16 = 60 B
-    flops: 2 slab tests per inner visit (2 x 22), Moller-Trumbore 48 per triangle, ray set-up 10.
+    per inner-node step: two child boxes (48 B) + two child indices (8 B)             = 56 B
+    per triangle test:   leaf index entry (4 B) + a, e1, e2 (36 B)                     = 40 B
+    per queued ray:      ray state in / closest-hit record out                         = 64 B
+    flops: 22 per box test, 48 per triangle test (Moeller-Trumbore incl. the division).
     """
-    b = 64 * st["trav_inner"] + 40 * st["trav_tri"] + 60 * st["trav_rays"]
-    f = 22 * st["trav_box"] + 48 * st["trav_tri"] + 10 * st["trav_rays"]
+    b = 56 * st["trav_inner"] + 40 * st["trav_tri"] + 64 * st["trav_rays"]
+    f = 22 * st["trav_box"] + 48 * st["trav_tri"]
     return b, f
 
 
@@ -72,7 +73,7 @@ def main():
     ap.add_argument("--textures", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=1)
+    ap.add_argument("--cpu-spp", type=int, default=24)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -176,7 +177,7 @@ def main():
     tr = max(1, cd["trav_rays"])
     workload_key = f"{args.scene}:{cam.width}x{cam.height}:spp{spp}:tex{args.textures}"
     roofline = {
-        "kernel": "wf_traverse_kernel<0,1,3>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+        "kernel": "wf_traverse_coop_kernel<0,3,32,32,1>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": load_traffic(workload_key),
         "launch_ms": round(launch_ms, 4), "launches": trav_n.value, "bytes_per_launch": round(b_launch),
         "traversals_per_launch": round(cd["trav_rays"] / n_launch), "bytes_per_traversal": round(b_total / tr, 1),
@@ -186,6 +187,9 @@ def main():
         "per_traversal": {k: round(cd[k] / tr, 3) for k in ("trav_inner", "trav_box", "trav_tri", "trav_leaf")},
         "segment_kernel": {"launch_ms": round(float(seg_ms.value) / max(1, seg_n.value), 4), "launches": seg_n.value},
         "step_kernel_ms": round(float(kernel_ms.value) / args.steps, 3),
+        "note": "achieved = logical bytes the traversal consumes / launch time; the 21 MB tree + triangle set is served by "
+                "L1/L2/Infinity Cache, so this can exceed the HBM peak - traffic is the measured L2-miss side, valu the "
+                "compute bound that actually binds (DESIGN.md, Roofline)",
     }
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------

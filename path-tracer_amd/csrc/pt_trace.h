@@ -83,6 +83,26 @@ PT_DEV bool tri_test(const Ray& r, f3 va, f3 e1, f3 e2, float& res_t, float& ru,
 	return false;
 }
 
+// The same test without early exits, for callers whose lanes test DIFFERENT triangles against one
+// ray (a wave pays for its slowest lane anyway, so the exits only add exec-mask bookkeeping and
+// serialise the operand loads behind them). Each rejection is the reference's comparison, negated
+// as a whole, so NaN/inf operands (a ~ 0 gives f = inf) take the same decisions as the early returns.
+PT_DEV bool tri_test_flat(const Ray& r, f3 va, f3 e1, f3 e2, float& res_t, float& ru, float& rv) {
+	const f3 h = cross3(r.d, e2);
+	const float a = dot3(e1, h);
+	const bool ok_a = !(a > -PT_TRI_EPSILON && a < PT_TRI_EPSILON);
+	const float f = 1.0f / a;
+	const f3 s = r.o - va;
+	const float u = f * dot3(s, h);
+	const bool ok_u = !(u < 0.0f || u > 1.0f);
+	const f3 q = cross3(s, e1);
+	const float v = f * dot3(r.d, q);
+	const bool ok_v = !(v < 0.0f || u + v > 1.0f);
+	const float t = f * dot3(e2, q);
+	res_t = t; ru = u; rv = v;
+	return (ok_a & ok_u) & (ok_v & (t > PT_TRI_EPSILON));
+}
+
 // reference: src/intersect.cuh:59-83 testSphereIntersection
 PT_DEV bool sphere_test(const Ray& r, float rad, f3 center, f3& hit_point, f3& hit_norm, float& t_out) {
 	f3 op = center - r.o;

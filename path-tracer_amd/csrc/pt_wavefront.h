@@ -457,7 +457,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 // Round structure (wave-uniform control flow throughout):
 //   refill idle lanes from the wave's queue chunk -> all lanes descend until each holds a leaf or is
 //   done -> leaves are processed two at a time -> owners pop their stacks.
-template <int FLAGS, int OCC, int CHUNK>
+template <int FLAGS, int OCC, int CHUNK, int ATHRESH, int FLAT>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
 	extern __shared__ int lds_stack[];
 	const int tid = threadIdx.x, lane = tid & 63, sub = lane & 31;
@@ -536,7 +536,12 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 		if (__ballot(state != IDLE) == 0ull) break;
 
 		// ---- descent: every lane walks inner nodes until it holds a leaf or its traversal ends ----
-		while (__ballot(state == DESCEND) != 0ull) {
+		// The loop stops once no more than ATHRESH lanes are still on their way: waiting for the last
+		// few would idle the rest (measured with ATHRESH = 0: 19 % of the lanes busy per iteration);
+		// the stragglers simply carry on in the next round, next to the lanes that popped.
+		for (int iter = 0; ; ++iter) {
+			const int n_desc = (int)__popcll(__ballot(state == DESCEND));
+			if (n_desc == 0 || (iter > 0 && n_desc <= ATHRESH)) break;
 			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; dg1 += 64; } }
 			if (state == DESCEND) {
 				if (FLAGS & PT_F_STATS) { act++; dg0++; }
@@ -614,7 +619,8 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				float t = 0.0f, u = 0.0f, v = 0.0f;
 				if (i < count) {
 					const float4 a = pa[first + i], e1 = pe1[first + i], e2 = pe2[first + i];
-					hit = tri_test(br, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t, u, v);
+					if (FLAT) hit = tri_test_flat(br, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t, u, v);
+					else hit = tri_test(br, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t, u, v);
 					if (FLAGS & PT_F_STATS) { act++; dg2++; }
 				}
 				if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; dg3 += 64; } }

@@ -564,22 +564,21 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				const int obj = scene->big_object[k];
 				prof_mark(ctx, 0);
 #define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
-#define COOP(F, O, C) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
-				// <stats, next-triangle prefetch, min waves/SIMD the register allocator must allow, queue chunk>
-				// PTX_TRAV_VARIANT selects the alternatives for A/B runs (tools/sweep.sh)
+#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
+				// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
+				// descent threshold, branch-free triangle test>. PTX_TRAV_VARIANT / ptx_ctx_tune select the
+				// earlier designs for A/B runs (tools/sweep.sh); measured on the bench workload (Mrays/s):
+				//   0: 1290   1: 700 (one ray per lane, static queue split)   2: 755 (same, dynamic chunks)
+				//   3: 940 (cooperative, descent waits for every lane)        4: 1190 (cooperative, early-exit test)
 				if (collect_stats) {
-					if (ctx->trav_variant >= 10) COOP(PT_F_STATS, 4, 128); else TRAV(PT_F_STATS, 1, 3, 128);
+					if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
+					else COOP(PT_F_STATS, 3, 32, 32, 1);
 				} else switch (ctx->trav_variant) {
-					case 1: TRAV(0, 1, 3, 0); break;     // static split (round-1 first version)
+					case 1: TRAV(0, 1, 3, 0); break;
 					case 2: TRAV(0, 1, 3, 64); break;
-					case 3: TRAV(0, 1, 3, 256); break;
-					case 4: TRAV(0, 1, 4, 128); break;
-					case 5: TRAV(0, 0, 8, 128); break;
-					case 10: COOP(0, 4, 128); break;
-					case 11: COOP(0, 6, 128); break;
-					case 12: COOP(0, 8, 128); break;
-					case 13: COOP(0, 8, 0); break;
-					default: TRAV(0, 1, 3, 128); break;
+					case 3: COOP(0, 3, 32, 0, 1); break;
+					case 4: COOP(0, 3, 32, 32, 0); break;
+					default: COOP(0, 3, 32, 32, 1); break;
 				}
 #undef TRAV
 #undef COOP
