@@ -1,0 +1,124 @@
+"""Size-independent properties of the HIP path at the bench workload's full size, and edge cases
+(ragged resolutions, empty scenes, bounce limits). All through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import gpuops
+
+pytestmark = pytest.mark.gpu
+
+
+def _tune(pt, ctx, key, value):
+    pt.check(pt.lib().ptx_ctx_tune(ctx, key, value))
+
+
+def test_full_size_sample_ranges_compose_and_schedules_agree(pt, ctx):
+    """1920x1080 Lamborghini: [0,4) in one call == [0,2) then [2,4) == any wavefront batch size ==
+    the one-lane-per-pixel megakernel, bit for bit; rays/paths counters agree as well."""
+    desc, cam = pt.load_scene("lamborghini", width=1920, height=1080, textures=1)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    base, st = gpuops.render(ctx, scene, cam, 0, 4, 11)
+    assert st.paths == 4 * 1920 * 1080 and st.paths <= st.rays <= 5 * st.paths
+    assert np.isfinite(base).all() and base.min() >= 0 and (base[:, 3] == 0).all() and base[:, :3].max() > 0
+    two, st2 = gpuops.render(ctx, scene, cam, 0, 4, 11, batch=2)
+    assert np.array_equal(base.view(np.uint32), two.view(np.uint32)) and st2.rays == st.rays
+    try:
+        for wb in (1, 3):
+            _tune(pt, ctx, b"wf_batch", wb)
+            acc, s = gpuops.render(ctx, scene, cam, 0, 4, 11)
+            assert np.array_equal(base.view(np.uint32), acc.view(np.uint32)), f"wf_batch {wb}"
+            assert s.rays == st.rays
+        _tune(pt, ctx, b"wf_batch", -1)
+        _tune(pt, ctx, b"megakernel", 1)
+        mk, sm = gpuops.render(ctx, scene, cam, 0, 1, 11)
+        _tune(pt, ctx, b"megakernel", 0)
+        wf, sw = gpuops.render(ctx, scene, cam, 0, 1, 11)
+        assert np.array_equal(mk.view(np.uint32), wf.view(np.uint32)) and sm.rays == sw.rays
+    finally:
+        _tune(pt, ctx, b"wf_batch", -1)
+        _tune(pt, ctx, b"megakernel", -1)
+    # determinism: same call twice
+    again, _ = gpuops.render(ctx, scene, cam, 0, 4, 11)
+    assert np.array_equal(base.view(np.uint32), again.view(np.uint32))
+    # a different seed changes the image
+    other, _ = gpuops.render(ctx, scene, cam, 0, 4, 12)
+    assert not np.array_equal(base, other)
+
+
+def test_full_size_spp_split_partials_sum_to_the_whole(pt, ctx):
+    """What two ranks do (disjoint sample ranges, then SUM): equal to the single-GPU buffer up to float
+    summation order."""
+    desc, cam = pt.load_scene("lamborghini", width=1920, height=1080, textures=1)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    whole, st = gpuops.render(ctx, scene, cam, 0, 8, 5)
+    a, sa = gpuops.render(ctx, scene, cam, 0, 4, 5)
+    b, sb = gpuops.render(ctx, scene, cam, 4, 4, 5)
+    assert sa.rays + sb.rays == st.rays and sa.paths + sb.paths == st.paths
+    s = a + b
+    scale = np.maximum(np.abs(whole), 1e-3)
+    assert (np.abs(s - whole) / scale).max() < 1e-5
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (7, 5), (67, 45), (130, 3)])
+def test_ragged_resolutions_match_oracle(pt, orc, ctx, w, h):
+    desc, cam = pt.load_scene("teapot", width=w, height=h)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 0, 3, 9)
+    acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 3, 9, stats=True)
+    assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32))
+    assert (st_o.rays, st_o.paths, st_o.n_tri) == (st_g.rays, st_g.paths, st_g.n_tri)
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 2, 17])
+def test_bounce_limits_match_oracle(pt, orc, ctx, bounces):
+    desc, cam = pt.load_scene("geoms", width=64, height=48, bounces=bounces)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 0, 4, 2)
+    acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 4, 2, stats=True)
+    assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32))
+    assert st_o.rays == st_g.rays
+    if bounces == 0:
+        assert acc_g.max() == 0 and st_g.rays == 0
+
+
+def test_empty_scene_renders_black(pt, orc, ctx, tmp_path):
+    p = tmp_path / "empty.json"
+    p.write_text('{"camera": {"pixelWidth": 32, "pixelHeight": 24, "direction": [0,0,-1], "up": [0,1,0], "position": [0,0,0],'
+                 ' "screenDist": 1, "screenHeight": 1}, "objects": [{"type": "sphere", "render": false, "radius": 1,'
+                 ' "position": [0,0,-5], "material": {"type": "lumi", "Kd": [1], "Ke": [5]}}]}')
+    H = pt.host()
+    H.pth_set_device_upload(1)
+    assert H.pth_scene_load(str(p).encode(), 0, 0, -1, 0, 0, -1) == 0, H.pth_last_error()
+    desc = H.pth_scene_desc()
+    assert desc.contents.num_objects == 0
+    cam = pt.PtxCamera()
+    assert H.pth_camera_get(C.byref(cam)) == 0
+    scene = H.pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc, st = gpuops.render(ctx, scene, cam, 0, 2, 1, stats=True)
+    assert acc.max() == 0 and st.paths == 2 * 32 * 24 and st.rays == st.paths
+    acc_o, st_o = orc.render(desc, cam, 0, 2, 1)
+    assert acc_o.max() == 0 and st_o.rays == st.rays
+
+
+def test_errors_are_reported_not_swallowed(pt, ctx):
+    L = pt.lib()
+    desc, cam = pt.load_scene("geoms", width=16, height=16)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    assert L.ptx_render_samples(ctx, scene, -1, 1, 0, 0) != 0 and b"sample range" in L.ptx_last_error()
+    assert L.ptx_render_samples(ctx, None, 0, 1, 0, 0) != 0
+    assert L.ptx_ctx_tune(ctx, b"no_such_knob", 1) != 0
+    bad = pt.PtxCamera()
+    C.memmove(C.byref(bad), C.byref(cam), C.sizeof(cam))
+    bad.width = 0
+    assert L.ptx_render_init(ctx, C.byref(bad), None) != 0
+    gpuops.render_init(ctx, cam)   # context still usable afterwards
+    acc, _ = gpuops.render(ctx, scene, cam, 0, 1, 0)
+    assert acc.max() > 0
