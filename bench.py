@@ -64,12 +64,12 @@ def load_traffic(workload_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="lamborghini")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=8)
+    ap.add_argument("--spp-per-step", type=int, default=64)
     ap.add_argument("--textures", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,7 +177,7 @@ def main():
     tr = max(1, cd["trav_rays"])
     workload_key = f"{args.scene}:{cam.width}x{cam.height}:spp{spp}:tex{args.textures}"
     roofline = {
-        "kernel": "wf_traverse_coop_kernel<0,3,32,32,1>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+        "kernel": "wf_traverse_coop_kernel<0,7,64,32,1>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": load_traffic(workload_key),
         "launch_ms": round(launch_ms, 4), "launches": trav_n.value, "bytes_per_launch": round(b_launch),
         "traversals_per_launch": round(cd["trav_rays"] / n_launch), "bytes_per_traversal": round(b_total / tr, 1),

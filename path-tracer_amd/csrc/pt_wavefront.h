@@ -595,6 +595,78 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 
 		// ---- leaves: two owners per step, one per half-wave ----
 		unsigned long long m = __ballot(state == LEAF);
+		if (FLAT == 2) {
+			// Two steps (four owners) in flight: the broadcasts and triangle loads of step B are issued
+			// before step A is computed, so a wave has two independent memory round trips outstanding
+			// instead of one load -> wait -> compute chain per step.
+			struct Step {
+				int l0, l1;
+				float ox, oy, oz, dx, dy, dz;
+				float4 a, e1, e2;
+				bool valid;
+			};
+			auto pick = [&](Step& st) {
+				st.l0 = (int)__ffsll((long long)m) - 1;
+				m &= m - 1ull;
+				st.l1 = -1;
+				if (m != 0ull) { st.l1 = (int)__ffsll((long long)m) - 1; m &= m - 1ull; }
+			};
+			auto issue = [&](Step& st, int base) {
+				const bool on = !upper || st.l1 >= 0;
+				const int src = (upper && st.l1 >= 0) ? st.l1 : st.l0;
+				st.ox = __shfl(ray.o.x, src, 64); st.oy = __shfl(ray.o.y, src, 64); st.oz = __shfl(ray.o.z, src, 64);
+				st.dx = __shfl(ray.d.x, src, 64); st.dy = __shfl(ray.d.y, src, 64); st.dz = __shfl(ray.d.z, src, 64);
+				const int first = __shfl(leaf_first, src, 64);
+				const int count = __shfl(leaf_count, src, 64);
+				const int i = base + sub;
+				st.valid = on && i < count;
+				int idx = first + (i < count ? i : 0);          // always a loadable address: no branch before the loads
+				idx = idx < sc.num_tris ? idx : sc.num_tris - 1;
+				st.a = pa[idx]; st.e1 = pe1[idx]; st.e2 = pe2[idx];
+			};
+			auto finish = [&](const Step& st, int base) {
+				Ray br;
+				br.o = mk3(st.ox, st.oy, st.oz);
+				br.d = mk3(st.dx, st.dy, st.dz);
+				float t, u, v;
+				bool hit = tri_test_flat(br, mk3(st.a.x, st.a.y, st.a.z), mk3(st.e1.x, st.e1.y, st.e1.z), mk3(st.e2.x, st.e2.y, st.e2.z), t, u, v);
+				hit = hit && st.valid;
+				if (FLAGS & PT_F_STATS) { if (st.valid) { act++; dg2++; } if (lane == 0) { tot += 64; dg3 += 64; } }
+				const unsigned long long hm = __ballot(hit);
+				uint32_t h0 = (uint32_t)hm, h1 = (uint32_t)(hm >> 32);
+				while ((h0 | h1) != 0u) {
+					const int w0 = h0 ? (int)__ffs((int)h0) - 1 : 0;
+					const int w1 = h1 ? 32 + (int)__ffs((int)h1) - 1 : 32;
+					const bool second = lane == st.l1;
+					const int w = second ? w1 : w0;
+					const float tt = __shfl(t, w, 64), uu = __shfl(u, w, 64), vv = __shfl(v, w, 64);
+					const bool mine = (lane == st.l0 && h0 != 0u) || (second && h1 != 0u);
+					if (mine) {
+						ts.intersects = true;
+						if (tt < ts.tmin) { ts.tmin = tt; ts.tri = leaf_first + base + (w & 31); ts.bu = uu; ts.bv = vv; }
+					}
+					h0 &= h0 - 1u;
+					h1 &= h1 - 1u;
+				}
+			};
+			auto extra_passes = [&](Step& st) {   // leaves with more than 32 triangles (rare)
+				const int c0 = __builtin_amdgcn_readlane(leaf_count, st.l0);
+				const int c1 = st.l1 >= 0 ? __builtin_amdgcn_readlane(leaf_count, st.l1) : 0;
+				const int cmax = c0 > c1 ? c0 : c1;
+				for (int base = 32; base < cmax; base += 32) { issue(st, base); finish(st, base); }
+			};
+			while (m != 0ull) {
+				Step A, B;
+				pick(A);
+				const bool has_b = m != 0ull;
+				issue(A, 0);
+				if (has_b) { pick(B); issue(B, 0); }
+				finish(A, 0);
+				if (has_b) finish(B, 0);
+				extra_passes(A);
+				if (has_b) extra_passes(B);
+			}
+		} else
 		while (m != 0ull) {
 			const int l0 = (int)__ffsll((long long)m) - 1;
 			m &= m - 1ull;
