@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--textures", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: every rank uses cuda:0 and the collective runs over gloo, to exercise the N>1 "
+                         "code path on a one-GPU box (the reported number is then meaningless)")
     ap.add_argument("--cpu-spp", type=int, default=24)
     args = ap.parse_args()
 
@@ -89,10 +92,15 @@ def main():
     L, H = pt.lib(), pt.host()
     if not pt.gpu_available():
         raise SystemExit("bench.py needs an MI355X: libptx_hip.so sees no HIP device (there is no CPU path)")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     H.pth_set_device(local_rank)
     H.pth_set_seed(args.seed)

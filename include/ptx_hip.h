@@ -244,6 +244,11 @@ int ptx_bsdf_eval(PtxCtx* ctx, int n, PtxBsdfCase* cases_host);
  * writes width*height*3 floats (rgb radiance of global sample `sample`). */
 int ptx_radiance_sample(PtxCtx* ctx, const PtxScene* scene, int sample, uint64_t seed, float* rgb_host);
 
+/* Device self-test (no reference counterpart): the triangle test's 5-instruction reciprocal is compared with the
+ * IEEE quotient 1.0f / a for EVERY float with lo <= |a| <= hi; reports how many were checked, how many differ
+ * and the bit pattern of the first that does (0xffffffff if none). */
+int ptx_selftest_rcp(PtxCtx* ctx, float lo, float hi, uint64_t* checked, uint64_t* mismatches, uint32_t* first_bad_bits);
+
 #ifdef __cplusplus
 }
 #endif

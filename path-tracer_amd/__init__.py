@@ -97,7 +97,7 @@ PTX_SYMBOLS = [
     "ptx_scene_upload", "ptx_scene_free", "ptx_scene_device_bytes", "ptx_render_init", "ptx_render_set_camera",
     "ptx_render_cleanup", "ptx_accum_clear", "ptx_render_samples", "ptx_render_sync", "ptx_accum_device_ptr",
     "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_stats_get", "ptx_stats_reset",
-    "ptx_wavefront_counts", "ptx_ctx_tune", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample",
+    "ptx_wavefront_counts", "ptx_ctx_tune", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample", "ptx_selftest_rcp",
 ]
 
 _lib = None
@@ -142,6 +142,7 @@ def lib():
         L.ptx_stats_reset.argtypes = [vp]
         L.ptx_wavefront_counts.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.ptx_ctx_tune.argtypes = [vp, C.c_char_p, i32]
+        L.ptx_selftest_rcp.argtypes = [vp, C.c_float, C.c_float, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.ptx_profile_enable.argtypes = [vp, i32]
         L.ptx_profile_get.argtypes = [vp, fp, C.POINTER(C.c_int32), fp, C.POINTER(C.c_int32)]
         L.ptx_timer_begin.argtypes = [vp]

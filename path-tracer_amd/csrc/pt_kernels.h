@@ -253,3 +253,26 @@ __global__ __launch_bounds__(PT_BLOCK) void tonemap_kernel(uchar4* __restrict__ 
 	p.z = (unsigned char)(255.0f * powf(fmaxf(0.0f, fminf(a.z * inv_iter, 1.0f)), gamma));
 	out[i] = p;
 }
+
+// Exhaustive check of pt_rcp_newton against the IEEE quotient over all float bit patterns with lo <= |a| <= hi.
+__global__ __launch_bounds__(PT_BLOCK) void rcp_selftest_kernel(float lo, float hi, unsigned long long* out /* checked, mismatches, first bad */) {
+	unsigned long long checked = 0, bad = 0;
+	unsigned long long first = ~0ull;
+	const unsigned long long stride = (unsigned long long)gridDim.x * PT_BLOCK;
+	for (unsigned long long b = (unsigned long long)blockIdx.x * PT_BLOCK + threadIdx.x; b < (1ull << 32); b += stride) {
+		const float a = __uint_as_float((uint32_t)b);
+		const float m = __builtin_fabsf(a);
+		if (!(m >= lo && m <= hi)) continue;
+		checked++;
+		const float want = 1.0f / a;
+		const float got = pt_rcp_newton(a);
+		if (__float_as_uint(want) != __float_as_uint(got)) { bad++; if (b < first) first = b; }
+	}
+	checked = wave_sum_u64(checked);
+	bad = wave_sum_u64(bad);
+	if (first != ~0ull) atomicMin(&out[2], first);
+	if ((threadIdx.x & 63) == 0) {
+		atomicAdd(&out[0], checked);
+		atomicAdd(&out[1], bad);
+	}
+}

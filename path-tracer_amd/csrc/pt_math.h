@@ -40,6 +40,27 @@ PT_DEV f3 cross3(f3 a, f3 b) {
 // (about 1 ulp) on gfx950 with ROCm 7.2; __builtin_sqrtf gets the compiler's fix-up sequence.
 PT_DEV float pt_sqrt(float x) { return __builtin_sqrtf(x); }
 PT_DEV float length3(f3 v) { return pt_sqrt(dot3(v, v)); }
+
+// 1.0f / a in 5 instructions instead of the 10 of the IEEE division sequence: v_rcp_f32 (1 ulp) and
+// two Newton steps in fma arithmetic. EQUAL to the correctly rounded quotient for every float with
+// PT_RCP_LO <= |a| <= PT_RCP_HI: ptx_selftest_rcp compares all ~2^31 of them on the device
+// (tests/test_gpu_parity.py::test_fast_reciprocal_is_exact). Callers fall back to 1.0f / a outside.
+#define PT_RCP_LO 5.0e-8f                  /* = PT_TRI_EPSILON: smaller determinants are rejected before use */
+#define PT_RCP_HI 8.5070591730234616e37f   /* 2^126: beyond it the quotient is subnormal */
+PT_DEV float pt_rcp_newton(float a) {
+	float r = __builtin_amdgcn_rcpf(a);
+	float e = __builtin_fmaf(-a, r, 1.0f);
+	r = __builtin_fmaf(e, r, r);
+	e = __builtin_fmaf(-a, r, 1.0f);
+	r = __builtin_fmaf(e, r, r);
+	return r;
+}
+// The IEEE quotient 1.0f / a for |a| >= PT_RCP_LO (smaller |a|: unspecified, callers discard it). Determinants
+// beyond 2^126 do not occur in practice; if one lane of the wave has one, the wave takes the division.
+PT_DEV float pt_rcp_det(float a) {
+	if (__ballot(__builtin_fabsf(a) > PT_RCP_HI) != 0ull) return 1.0f / a;
+	return pt_rcp_newton(a);
+}
 PT_DEV f3 normalize3(f3 v) {
 	float invLen = 1.0f / pt_sqrt(dot3(v, v));
 	return v * invLen;

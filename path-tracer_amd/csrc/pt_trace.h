@@ -68,7 +68,7 @@ PT_DEV bool tri_test(const Ray& r, f3 va, f3 e1, f3 e2, float& res_t, float& ru,
 	f3 h = cross3(r.d, e2);
 	float a = dot3(e1, h);
 	if (a > -PT_TRI_EPSILON && a < PT_TRI_EPSILON) return false;
-	float f = 1.0f / a;
+	float f = pt_rcp_det(a); // == 1.0f / a bit for bit (pt_math.h)
 	f3 s = r.o - va;
 	float u = f * dot3(s, h);
 	if (u < 0.0f || u > 1.0f) return false;
@@ -91,7 +91,7 @@ PT_DEV bool tri_test_flat(const Ray& r, f3 va, f3 e1, f3 e2, float& res_t, float
 	const f3 h = cross3(r.d, e2);
 	const float a = dot3(e1, h);
 	const bool ok_a = !(a > -PT_TRI_EPSILON && a < PT_TRI_EPSILON);
-	const float f = 1.0f / a;
+	const float f = pt_rcp_det(a); // == 1.0f / a bit for bit wherever ok_a holds (pt_math.h)
 	const f3 s = r.o - va;
 	const float u = f * dot3(s, h);
 	const bool ok_u = !(u < 0.0f || u > 1.0f);

@@ -807,6 +807,23 @@ extern "C" int ptx_bsdf_eval(PtxCtx* ctx, int n, PtxBsdfCase* cases_host) {
 	return PTX_OK;
 }
 
+extern "C" int ptx_selftest_rcp(PtxCtx* ctx, float lo, float hi, uint64_t* checked, uint64_t* mismatches, uint32_t* first_bad_bits) {
+	if (!ctx || !checked || !mismatches || !first_bad_bits) return fail(PTX_E_INVALID, "ptx_selftest_rcp: NULL argument");
+	HIP_TRY(hipSetDevice(ctx->device));
+	DevBuf d;
+	HIP_TRY(hipMalloc(&d.p, 3 * sizeof(unsigned long long)));
+	unsigned long long h[3] = {0, 0, ~0ull};
+	HIP_TRY(hipMemcpyAsync(d.p, h, sizeof(h), hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(rcp_selftest_kernel, dim3(256 * 16), dim3(PT_BLOCK), 0, ctx->stream, lo, hi, (unsigned long long*)d.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(h, d.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	*checked = h[0];
+	*mismatches = h[1];
+	*first_bad_bits = (uint32_t)h[2];
+	return PTX_OK;
+}
+
 extern "C" int ptx_radiance_sample(PtxCtx* ctx, const PtxScene* scene, int sample, uint64_t seed, float* rgb_host) {
 	int rc = check_scene(ctx, scene, "ptx_radiance_sample");
 	if (rc != PTX_OK) return rc;

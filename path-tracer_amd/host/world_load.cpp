@@ -198,7 +198,9 @@ static Material* loadMaterialsToHost(const ObjScene& oscene) {
 			REPORT(info("    Loading texture: %s", texture_path->c_str()));
 			mat_ptr[i].cuda_texture_obj = loadTexture(*texture_path);
 			if (mat_ptr[i].cuda_texture_obj < 0) {
-				printf("    Warning: texture load failed: %s\n", texture_path->c_str());
+				// printed once per file and process: lp560.mtl names 19 absent TGAs from 41 materials
+				static std::map<std::string, int>* warned = new std::map<std::string, int>();
+				if ((*warned)[*texture_path]++ == 0) printf("    Warning: texture load failed: %s\n", texture_path->c_str());
 				REPORT(warning("    Warning: texture load failed: %s", texture_path->c_str()));
 			}
 		}

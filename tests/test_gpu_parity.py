@@ -156,3 +156,15 @@ def test_full_size_lamborghini_matches_oracle(pt, orc, ctx):
                     assert getattr(st_o, k) == getattr(st_g, k), f"variant {variant}: counter {k}: oracle {getattr(st_o, k)} gpu {getattr(st_g, k)}"
     finally:
         pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", -1))
+
+
+def test_fast_reciprocal_is_exact(pt, ctx):
+    """The triangle test replaces 1.0f / det by v_rcp_f32 + two fma Newton steps. That is only legitimate if the
+    result is the IEEE quotient bit for bit, so the device compares EVERY float in the admitted range
+    (|det| from the rejection threshold 5e-8 up to 2^126): 2.5 billion values, no mismatch allowed."""
+    c, m, f = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    pt.check(pt.lib().ptx_selftest_rcp(ctx, 5.0e-8, 2.0 ** 126, C.byref(c), C.byref(m), C.byref(f)))
+    assert c.value == 2521989336 and m.value == 0, f"{m.value} of {c.value} reciprocals differ, first bits {f.value:#010x}"
+    # outside the range the shortcut is wrong, which is why pt_rcp_det falls back to the division there
+    pt.check(pt.lib().ptx_selftest_rcp(ctx, 2.0 ** 126 * 1.0001, 3.0e38, C.byref(c), C.byref(m), C.byref(f)))
+    assert m.value > 0
