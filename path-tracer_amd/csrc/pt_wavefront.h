@@ -33,7 +33,9 @@
 #include "pt_kernels.h"
 
 #define PT_MAX_BIG 31   // multi-node meshes with a traversal queue (flag bits 1..31 of a 32-bit word)
-#define WF_ROUNDS 4
+#ifndef WF_ROUNDS
+#define WF_ROUNDS 2
+#endif
 #define PT_WF_MAX_BOUNCES 64
 
 struct WfParams {
@@ -171,20 +173,30 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCa
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
 	uint64_t n_rays = 0, n_paths = 0, c_hm = 0, c_hs = 0, c_ht = 0;
 
-	// List appends (next live list, traversal queues) are aggregated over WF_ROUNDS x 256 paths per
-	// workgroup: ONE atomic per list per 1024 paths. (One atomic per wave serialised the whole chip on
-	// a single counter address: 91 % of this kernel's wave time was spent waiting, profiles/r01b.)
-	__shared__ int sh_path[WF_ROUNDS * PT_BLOCK];
-	__shared__ uint32_t sh_flags[WF_ROUNDS * PT_BLOCK];
+	// A workgroup takes WF_ROUNDS x 256 paths per iteration and works in two phases:
+	//   1. generate / shade: one path per lane; the rays that go on are COMPACTED into LDS
+	//      (a third to two thirds of the paths end at each bounce, so without this most lanes of
+	//      the intersection code below would idle next to a few live ones);
+	//   2. intersect: one surviving ray per lane, full waves; writes the path state and the list flags.
+	// List appends (next live list, traversal queues) are aggregated over the whole iteration: ONE atomic
+	// per list per iteration. (One atomic per wave serialised the whole chip on a single counter
+	// address: 91 % of this kernel's wave time was spent waiting, profiles/r01_baseline_*.)
+	constexpr int CAP = WF_ROUNDS * PT_BLOCK;
+	__shared__ float sh_ray[9][CAP];          // origin, direction, mask of the compacted rays (SoA: conflict-free)
+	__shared__ int sh_path[CAP];
+	__shared__ uint32_t sh_flags[CAP];
 	__shared__ int sh_cnt[1 + PT_MAX_BIG][WF_ROUNDS * (PT_BLOCK / 64)];
 	__shared__ int sh_base[1 + PT_MAX_BIG];
+	__shared__ int sh_n;
 	const int wave = tid >> 6;
 	const int nlists = 1 + wp.num_big;
+	if (tid == 0) sh_n = 0;
+	__syncthreads();
 
-	for (int blk0 = (int)blockIdx.x * (WF_ROUNDS * PT_BLOCK); blk0 < n_in; blk0 += (int)gridDim.x * (WF_ROUNDS * PT_BLOCK)) {
+	for (int blk0 = (int)blockIdx.x * CAP; blk0 < n_in; blk0 += (int)gridDim.x * CAP) {
+	// ---- phase 1: generate / shade, compact the survivors ---------------------------------------------
 	for (int round = 0; round < WF_ROUNDS; ++round) {
 		const int i = blk0 + round * PT_BLOCK + tid;
-		uint32_t flags = 0;
 		bool alive = i < n_in;
 		int path = 0;
 		if (alive) path = bounce == 0 ? i : live_in[i];
@@ -261,8 +273,38 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCa
 				}
 			}
 		}
+		// compact: slot = (LDS counter, one add per wave) + rank inside the wave
+		const unsigned long long am = __ballot(alive);
+		if (am != 0ull) {
+			int base = 0;
+			if (lane == 0) base = atomicAdd(&sh_n, (int)__popcll(am));
+			base = __builtin_amdgcn_readfirstlane(base);
+			if (alive) {
+				const int k = base + (int)__popcll(am & ((1ull << lane) - 1ull));
+				sh_ray[0][k] = ray.o.x; sh_ray[1][k] = ray.o.y; sh_ray[2][k] = ray.o.z;
+				sh_ray[3][k] = ray.d.x; sh_ray[4][k] = ray.d.y; sh_ray[5][k] = ray.d.z;
+				sh_ray[6][k] = mask.x; sh_ray[7][k] = mask.y; sh_ray[8][k] = mask.z;
+				sh_path[k] = path;
+			}
+		}
+	} // rounds
+		__syncthreads();
+		const int n_live = sh_n;
+		const int n_chunks = (n_live + PT_BLOCK - 1) / PT_BLOCK;
 
-		// ---- intersect the new segment with the cheap objects, enqueue it for the expensive ones ----
+	// ---- phase 2: intersect the new segments with the cheap objects, enqueue them for the expensive ones ----
+	for (int chunk = 0; chunk < n_chunks; ++chunk) {
+		const int k = chunk * PT_BLOCK + tid;
+		const bool alive = k < n_live;
+		uint32_t flags = 0;
+		Ray ray;
+		f3 mask = mk3(1.0f);
+		int path = 0;
+		if (alive) {
+			init_ray(ray, mk3(sh_ray[0][k], sh_ray[1][k], sh_ray[2][k]), mk3(sh_ray[3][k], sh_ray[4][k], sh_ray[5][k]));
+			mask = mk3(sh_ray[6][k], sh_ray[7][k], sh_ray[8][k]);
+			path = sh_path[k];
+		}
 		float best_dist = __builtin_huge_valf(), best_t = 0.0f, b_u = 0.0f, b_v = 0.0f;
 		int best_obj = -1, best_tri = -1;
 		if (alive) n_rays++;
@@ -305,34 +347,35 @@ __global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCa
 			wp.s1[path] = make_float4(ray.d.x, ray.d.y, ray.d.z, best_t);
 			wp.s2[path] = make_float4(mask.x, mask.y, mask.z, __int_as_float(best_obj));
 			wp.s3[path] = make_float4(__int_as_float(best_tri), b_u, b_v, 0.0f);
+			flags |= 1u;
 		}
-		if (alive) flags |= 1u;
-		sh_path[round * PT_BLOCK + tid] = path;
-		sh_flags[round * PT_BLOCK + tid] = flags;
+		sh_flags[chunk * PT_BLOCK + tid] = flags;
 		for (int L = 0; L < nlists; ++L) {
 			const unsigned long long m = __ballot((flags >> L) & 1u);
-			if (lane == 0) sh_cnt[L][round * (PT_BLOCK / 64) + wave] = (int)__popcll(m);
+			if (lane == 0) sh_cnt[L][chunk * (PT_BLOCK / 64) + wave] = (int)__popcll(m);
 		}
-	} // rounds
+	} // chunks
 		__syncthreads();
 		if (tid < nlists) {
 			int total = 0;
-			for (int j = 0; j < WF_ROUNDS * (PT_BLOCK / 64); ++j) {
+			for (int j = 0; j < n_chunks * (PT_BLOCK / 64); ++j) {
 				const int c = sh_cnt[tid][j];
 				sh_cnt[tid][j] = total;
 				total += c;
 			}
 			sh_base[tid] = total ? atomicAdd(&WF_CNT(wp, bounce, tid), total) : 0;
 		}
+		if (tid == 0) sh_n = 0;
 		__syncthreads();
-		for (int round = 0; round < WF_ROUNDS; ++round) {
-			const uint32_t f = sh_flags[round * PT_BLOCK + tid];
-			const int p = sh_path[round * PT_BLOCK + tid];
+		for (int chunk = 0; chunk < n_chunks; ++chunk) {
+			const int k = chunk * PT_BLOCK + tid;
+			const uint32_t f = sh_flags[k];
+			const int p = k < n_live ? sh_path[k] : 0;
 			for (int L = 0; L < nlists; ++L) {
 				const bool on = (f >> L) & 1u;
 				const unsigned long long m = __ballot(on);
 				if (on) {
-					const int slot = sh_base[L] + sh_cnt[L][round * (PT_BLOCK / 64) + wave] + (int)__popcll(m & ((1ull << lane) - 1ull));
+					const int slot = sh_base[L] + sh_cnt[L][chunk * (PT_BLOCK / 64) + wave] + (int)__popcll(m & ((1ull << lane) - 1ull));
 					if (L == 0) live_out[slot] = p; else wp.queue[L - 1][slot] = p;
 				}
 			}
