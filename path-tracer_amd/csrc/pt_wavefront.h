@@ -153,7 +153,8 @@ PT_DEV bool leaf_only_mesh(const DevScene& sc, const DevObject& ob, const Ray& r
 		const float4 g1 = sc.tri_geom[3 * (first + i) + 1];
 		const float4 g2 = sc.tri_geom[3 * (first + i) + 2];
 		float t, u, v;
-		if (tri_test(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
+		// every lane tests the SAME triangle with its own ray: early exits would only fire when all 64 agree
+		if (tri_test_flat(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
 			intersects = true;
 			if (t < tmin) { tmin = t; best_tri = first + i; bu = u; bv = v; }
 		}
@@ -161,8 +162,11 @@ PT_DEV bool leaf_only_mesh(const DevScene& sc, const DevObject& ob, const Ray& r
 	return intersects;
 }
 
+#ifndef WF_SEG_OCC
+#define WF_SEG_OCC 4
+#endif
 template <int FLAGS>
-__global__ __launch_bounds__(PT_BLOCK) void wf_segment_kernel(DevScene sc, DevCamera cam, WfParams wp) {
+__global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevScene sc, DevCamera cam, WfParams wp) {
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int bounce = wp.bounce;
 	const int n_in = bounce == 0 ? wp.n_total : WF_CNT(wp, bounce - 1, 0);

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_r01
 mkdir -p $O
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/trace.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/trace.log 2>&1 || exit 1
 echo trace done
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/fetch.log 2>&1 || exit 2
 echo fetch done
