@@ -9,7 +9,7 @@ import gpuops
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["example", "geoms", "teapot", "sky_map"]
+SCENES = ["example", "geoms", "teapot", "sky_map", "blender_comp"]
 
 
 def _secondary_rays(orc_hits, origins, dirs, rng, n):
@@ -89,7 +89,8 @@ def test_bsdf_bit_exact(pt, orc, ctx):
     assert len(bad) == 0, f"{len(bad)} BSDF cases differ, first {bad[:5]}"
 
 
-@pytest.mark.parametrize("name,tex", [("example", 0), ("geoms", 0), ("teapot", 0), ("sky_map", 1)])
+@pytest.mark.parametrize("name,tex", [("example", 0), ("geoms", 0), ("teapot", 0), ("sky_map", 1), ("blender_comp", 0),
+                                      ("blender_comp_open", 1), ("lamborghini_door", 1)])
 def test_radiance_and_accumulation_bit_exact(pt, orc, ctx, name, tex):
     desc, cam = pt.load_scene(name, width=64, height=48, textures=tex)
     scene = pt.host().pth_scene_device()
