@@ -165,6 +165,13 @@ def host():
         H.pth_last_error.restype = C.c_char_p
         H.pth_set_asset_root.argtypes = [C.c_char_p]
         H.pth_set_seed.argtypes = [C.c_uint64]
+        H.pth_checkpoint_save.argtypes = [C.c_char_p, C.c_int32]
+        H.pth_checkpoint_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
+        H.pth_autosave_due.argtypes = [C.c_int32, C.c_int32]
+        H.pth_checkpoint_write_file.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.POINTER(C.c_float)]
+        H.pth_checkpoint_read_file.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                               C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.c_int64]
+        H.pth_autosave_name.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]
         H.pth_scene_load.argtypes = [C.c_char_p, i32, i32, i32, i32, i32, i32]
         H.pth_scene_desc.restype = C.POINTER(PtxSceneDesc)
         H.pth_scene_tri_abc.restype = C.POINTER(C.c_float)

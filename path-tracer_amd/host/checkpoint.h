@@ -1,0 +1,25 @@
+// Float accumulation checkpoint / resume and the reference's autosave file naming.
+// The reference autosaves tone-mapped PNGs only (qt/mainwindow.cpp:93-99) and cannot resume; a
+// checkpoint here is the float4 accumulation buffer plus what is needed to continue the SAME sample
+// sequence: resolution, samples done, master seed. Because samples are added in index order, a run
+// resumed from a checkpoint is bit-identical to an uninterrupted one.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+struct AccumCheckpoint {
+	int32_t width, height;
+	int32_t samples_done;      // the buffer holds global samples [0, samples_done)
+	uint64_t seed;
+	std::vector<float> rgba;   // width * height * 4
+};
+
+bool saveCheckpoint(const std::string& path, const AccumCheckpoint& ck, std::string& err);
+bool loadCheckpoint(const std::string& path, AccumCheckpoint& ck, std::string& err);
+
+// reference: qt/mainwindow.cpp:93 — autosave when (iter % every == 0 || iter == 1) && iter > 0
+bool autosaveDue(int iter, int every);
+// reference: qt/mainwindow.cpp:96-97 — "<folder>/<name>_<dd-MM-yyyy>_<iter>spp.png" (date = today, local time)
+std::string autosaveFileName(const std::string& folder, const std::string& name, int iter);
+std::string autosaveFileName(const std::string& folder, const std::string& name, int iter, int day, int month, int year);

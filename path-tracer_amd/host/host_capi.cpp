@@ -210,3 +210,77 @@ extern "C" int pth_write_pfm(const char* path, int w, int h, const float* rgb) {
 	if (!writePFM(path, w, h, rgb, err)) { g_err = err; return PTX_E_INVALID; }
 	return PTX_OK;
 }
+
+// ---- checkpoint.h ---------------------------------------------------------------------------------
+#include "checkpoint.h"
+
+extern "C" int pth_checkpoint_save(const char* path, int samples_done) {
+	PtxCtx* ctx = kernelContext();
+	if (!ctx || !path) { g_err = "pth_checkpoint_save: no context / path"; return PTX_E_STATE; }
+	if (!sceneState.isLoaded()) { g_err = "pth_checkpoint_save: no scene"; return PTX_E_STATE; }
+	Scene sc = sceneState.clone();
+	AccumCheckpoint ck;
+	ck.width = sc.camera.projection.width;
+	ck.height = sc.camera.projection.height;
+	ck.samples_done = samples_done;
+	ck.seed = kernelSeed();
+	ck.rgba.resize((size_t)ck.width * ck.height * 4);
+	int rc = ptx_accum_download(ctx, ck.rgba.data());
+	if (rc != PTX_OK) { g_err = ptx_last_error(); return rc; }
+	std::string err;
+	if (!saveCheckpoint(path, ck, err)) { g_err = err; return PTX_E_INVALID; }
+	return PTX_OK;
+}
+
+extern "C" int pth_checkpoint_load(const char* path, int* samples_done) {
+	PtxCtx* ctx = kernelContext();
+	if (!ctx || !path || !samples_done) { g_err = "pth_checkpoint_load: no context / path"; return PTX_E_STATE; }
+	if (!sceneState.isLoaded()) { g_err = "pth_checkpoint_load: no scene"; return PTX_E_STATE; }
+	AccumCheckpoint ck;
+	std::string err;
+	if (!loadCheckpoint(path, ck, err)) { g_err = err; return PTX_E_INVALID; }
+	Scene sc = sceneState.clone();
+	if (ck.width != sc.camera.projection.width || ck.height != sc.camera.projection.height) {
+		g_err = "pth_checkpoint_load: checkpoint resolution differs from the scene's";
+		return PTX_E_INVALID;
+	}
+	if (ck.seed != kernelSeed()) { g_err = "pth_checkpoint_load: checkpoint was rendered with another seed"; return PTX_E_INVALID; }
+	int rc = ptx_accum_upload(ctx, ck.rgba.data());
+	if (rc != PTX_OK) { g_err = ptx_last_error(); return rc; }
+	*samples_done = ck.samples_done;
+	return PTX_OK;
+}
+
+extern "C" int pth_autosave_due(int iter, int every) { return autosaveDue(iter, every) ? 1 : 0; }
+
+extern "C" int pth_autosave_name(const char* folder, const char* name, int iter, int day, int month, int year, char* out, int out_len) {
+	if (!folder || !name || !out || out_len <= 0) return PTX_E_INVALID;
+	const std::string s = day > 0 ? autosaveFileName(folder, name, iter, day, month, year) : autosaveFileName(folder, name, iter);
+	if ((int)s.size() + 1 > out_len) return PTX_E_LIMIT;
+	memcpy(out, s.c_str(), s.size() + 1);
+	return PTX_OK;
+}
+
+extern "C" int pth_checkpoint_write_file(const char* path, int width, int height, int samples_done, uint64_t seed, const float* rgba) {
+	if (!path || !rgba || width <= 0 || height <= 0) { g_err = "pth_checkpoint_write_file: bad arguments"; return PTX_E_INVALID; }
+	AccumCheckpoint ck;
+	ck.width = width; ck.height = height; ck.samples_done = samples_done; ck.seed = seed;
+	ck.rgba.assign(rgba, rgba + (size_t)width * height * 4);
+	std::string err;
+	if (!saveCheckpoint(path, ck, err)) { g_err = err; return PTX_E_INVALID; }
+	return PTX_OK;
+}
+
+extern "C" int pth_checkpoint_read_file(const char* path, int* width, int* height, int* samples_done, uint64_t* seed, float* rgba,
+                                        int64_t rgba_capacity_floats) {
+	if (!path || !width || !height || !samples_done || !seed) { g_err = "pth_checkpoint_read_file: bad arguments"; return PTX_E_INVALID; }
+	AccumCheckpoint ck;
+	std::string err;
+	if (!loadCheckpoint(path, ck, err)) { g_err = err; return PTX_E_INVALID; }
+	*width = ck.width; *height = ck.height; *samples_done = ck.samples_done; *seed = ck.seed;
+	if (rgba) {
+		if ((int64_t)ck.rgba.size() > rgba_capacity_floats) { g_err = "pth_checkpoint_read_file: buffer too small"; return PTX_E_LIMIT; }
+		memcpy(rgba, ck.rgba.data(), ck.rgba.size() * sizeof(float));
+	}
+	return PTX_OK;
+}

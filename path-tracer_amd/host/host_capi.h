@@ -48,6 +48,16 @@ int pth_load_image_float(const char* path, int* w, int* h, int* channels, float*
 int pth_write_png(const char* path, int w, int h, int comp, const unsigned char* pixels, int mirror_h);
 int pth_write_pfm(const char* path, int w, int h, const float* rgb);
 
+
+/* checkpoint.h: float accumulation checkpoint / resume of the context's buffer, autosave naming */
+int pth_checkpoint_save(const char* path, int samples_done);          /* downloads the accumulation buffer */
+int pth_checkpoint_load(const char* path, int* samples_done);         /* checks resolution + seed, uploads */
+/* the file format itself, host memory only (rgba: width*height*4 floats) */
+int pth_checkpoint_write_file(const char* path, int width, int height, int samples_done, uint64_t seed, const float* rgba);
+int pth_checkpoint_read_file(const char* path, int* width, int* height, int* samples_done, uint64_t* seed, float* rgba, int64_t rgba_capacity_floats);
+int pth_autosave_due(int iter, int every);
+int pth_autosave_name(const char* folder, const char* name, int iter, int day, int month, int year, char* out, int out_len);
+
 #ifdef __cplusplus
 }
 #endif
