@@ -20,6 +20,13 @@
 //   tri_soa    the same triangles in the same order as three float4 planes of num_tris entries
 //              (a.xyz|prim id), (e1.xyz|0), (e2.xyz|0): the cooperative traversal kernel tests 32
 //              consecutive triangles of a leaf with 32 lanes, so each plane read is one contiguous 512 B
+//   tri_pair   every leaf run once more, padded to blocks of 32 slots (zero triangles never hit: their
+//              determinant is 0) and PAIR-INTERLEAVED: block = 5 planes x 16 float4 (1280 B); plane c,
+//              entry p = (X[p], X[p+16], Y[p], Y[p+16]) for components (X, Y) = (a.x, a.y), (a.z, e1.x),
+//              (e1.y, e1.z), (e2.x, e2.y), (e2.z, -). A lane of the cooperative kernel loads entry p of
+//              the five planes and holds triangles p and p+16 as register PAIRS, which is the operand
+//              form of the packed FP32 instructions. The leaf's node record carries its first block
+//              in q0.x (as int; a leaf's own q0..q2 are otherwise unused).
 //   tri_shade  4 x float4 per triangle (64 B), same order, touched once per mesh hit:
 //                s0 = (na.xyz, ta.x) s1 = (nb.xyz, ta.y) s2 = (nc.xyz, tb.x)
 //                s3 = (tb.y, tc.x, tc.y, int material_global_idx)
@@ -31,6 +38,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#define PT_PAIR_BLOCK_F4 80   /* float4 per tri_pair block: 5 planes x 16 */
 
 struct DevObject {
 	int32_t type;
@@ -56,6 +65,7 @@ struct DevScene {
 	const float4* nodes;
 	const float4* tri_geom;
 	const float4* tri_soa;  // the same triangles as three planes: a[], e1[], e2[] (float4 each, .w of plane 0 = prim id)
+	const float4* tri_pair;
 	const float4* tri_shade;
 	const float4* materials;
 	const DevTexture* textures;

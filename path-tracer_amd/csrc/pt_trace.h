@@ -103,6 +103,56 @@ PT_DEV bool tri_test_flat(const Ray& r, f3 va, f3 e1, f3 e2, float& res_t, float
 	return (ok_a & ok_u) & (ok_v & (t > PT_TRI_EPSILON));
 }
 
+// Two triangles against one ray per call, component pairs in 64-bit registers so that the
+// arithmetic issues as packed FP32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE results per instruction,
+// same rounding as the scalar forms; no contraction). Per component this is tri_test_flat, operation
+// for operation; bit k of the result = triangle k hit.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct f3x2 { v2f x, y, z; };
+PT_DEV v2f splat2(float s) { v2f r = {s, s}; return r; }
+PT_DEV f3x2 cross3x2(const f3x2& a, const f3x2& b) {
+	f3x2 r;
+	r.x = a.y * b.z - a.z * b.y;
+	r.y = a.z * b.x - a.x * b.z;
+	r.z = a.x * b.y - a.y * b.x;
+	return r;
+}
+PT_DEV v2f dot3x2(const f3x2& a, const f3x2& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV v2f rcp_det_x2(v2f a) {
+	const float hi = __builtin_fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y));
+	if (__ballot(hi > PT_RCP_HI) != 0ull) { v2f q = {1.0f / a.x, 1.0f / a.y}; return q; }
+	v2f r = {__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+	const v2f one = {1.0f, 1.0f};
+	v2f e = __builtin_elementwise_fma(-a, r, one);
+	r = __builtin_elementwise_fma(e, r, r);
+	e = __builtin_elementwise_fma(-a, r, one);
+	r = __builtin_elementwise_fma(e, r, r);
+	return r;
+}
+PT_DEV uint32_t tri_test_flat_x2(f3 o, f3 dir, const f3x2& va, const f3x2& e1, const f3x2& e2, v2f& res_t, v2f& ru, v2f& rv) {
+	f3x2 d, s;
+	d.x = splat2(dir.x); d.y = splat2(dir.y); d.z = splat2(dir.z);
+	const f3x2 h = cross3x2(d, e2);
+	const v2f a = dot3x2(e1, h);
+	const v2f f = rcp_det_x2(a);
+	s.x = splat2(o.x) - va.x; s.y = splat2(o.y) - va.y; s.z = splat2(o.z) - va.z;
+	const v2f u = f * dot3x2(s, h);
+	const f3x2 q = cross3x2(s, e1);
+	const v2f v = f * dot3x2(d, q);
+	const v2f t = f * dot3x2(e2, q);
+	const v2f uv = u + v;
+	res_t = t; ru = u; rv = v;
+	uint32_t bits = 0;
+#pragma unroll
+	for (int k = 0; k < 2; ++k) {
+		const bool ok_a = !(a[k] > -PT_TRI_EPSILON && a[k] < PT_TRI_EPSILON);
+		const bool ok_u = !(u[k] < 0.0f || u[k] > 1.0f);
+		const bool ok_v = !(v[k] < 0.0f || uv[k] > 1.0f);
+		if ((ok_a & ok_u) & (ok_v & (t[k] > PT_TRI_EPSILON))) bits |= 1u << k;
+	}
+	return bits;
+}
+
 // reference: src/intersect.cuh:59-83 testSphereIntersection
 PT_DEV bool sphere_test(const Ray& r, float rad, f3 center, f3& hit_point, f3& hit_norm, float& t_out) {
 	f3 op = center - r.o;

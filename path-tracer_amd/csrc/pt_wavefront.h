@@ -535,7 +535,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 
 	enum { IDLE = 0, DESCEND = 1, LEAF = 2 };
 	int state = IDLE;
-	int path = 0, leaf_first = 0, leaf_count = 0;
+	int path = 0, leaf_first = 0, leaf_count = 0, leaf_block = 0;
 	float cur_d = 0.0f;
 	Ray ray;
 	TravState ts;
@@ -601,6 +601,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				if (left == -1 && right == -1) {
 					leaf_first = __float_as_int(q3.z);
 					leaf_count = __float_as_int(q3.w);
+					leaf_block = __float_as_int(q0.x);
 					if (FLAGS & PT_F_STATS) {
 						cnt.n_leaf++;
 						cnt.n_tri += (uint32_t)leaf_count;
@@ -642,6 +643,82 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 
 		// ---- leaves: two owners per step, one per half-wave ----
 		unsigned long long m = __ballot(state == LEAF);
+		if (FLAT == 3) {
+			// Four owners per step, one per 16-lane quarter; every lane tests TWO triangles of its owner's run
+			// (slots p and p + 16 of a tri_pair block, pt_scene.h) with packed FP32 arithmetic. Padding
+			// slots hold zero triangles, which never hit, so no per-slot validity is needed.
+			const int quarter = lane >> 4, sub16 = lane & 15;
+			const float4* __restrict__ pp = sc.tri_pair;
+			while (m != 0ull) {
+				int l[4];
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					l[k] = -1;
+					if (m != 0ull) { l[k] = (int)__ffsll((long long)m) - 1; m &= m - 1ull; }
+				}
+				const int mine_l = quarter == 0 ? l[0] : quarter == 1 ? l[1] : quarter == 2 ? l[2] : l[3];
+				const bool on = mine_l >= 0;
+				const int src = on ? mine_l : l[0];
+				const f3 bo = mk3(__shfl(ray.o.x, src, 64), __shfl(ray.o.y, src, 64), __shfl(ray.o.z, src, 64));
+				const f3 bd = mk3(__shfl(ray.d.x, src, 64), __shfl(ray.d.y, src, 64), __shfl(ray.d.z, src, 64));
+				const int blk = __shfl(leaf_block, src, 64);
+				const int count_src = __shfl(leaf_count, src, 64);
+				const int count = on ? count_src : 0;
+				int cmax = 0;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) {
+					const int c = l[k] >= 0 ? __builtin_amdgcn_readlane(leaf_count, l[k]) : 0;
+					cmax = c > cmax ? c : cmax;
+				}
+				const bool owner = state == LEAF && ((lane == l[0]) | (lane == l[1]) | (lane == l[2]) | (lane == l[3]));
+				const int my_quarter = lane == l[0] ? 0 : lane == l[1] ? 1 : lane == l[2] ? 2 : 3;   // as an owner
+				for (int base = 0; base < cmax; base += 32) {
+					uint32_t hb = 0;
+					v2f t = {0.0f, 0.0f}, u = t, v = t;
+					if (base < count) {
+						const float4* bp = pp + ((size_t)(blk + (base >> 5)) * PT_PAIR_BLOCK_F4 + sub16);
+						const float4 c0 = bp[0], c1 = bp[16], c2 = bp[32], c3 = bp[48], c4 = bp[64];
+						f3x2 va, e1, e2;
+						va.x = (v2f){c0.x, c0.y}; va.y = (v2f){c0.z, c0.w}; va.z = (v2f){c1.x, c1.y};
+						e1.x = (v2f){c1.z, c1.w}; e1.y = (v2f){c2.x, c2.y}; e1.z = (v2f){c2.z, c2.w};
+						e2.x = (v2f){c3.x, c3.y}; e2.y = (v2f){c3.z, c3.w}; e2.z = (v2f){c4.x, c4.y};
+						hb = tri_test_flat_x2(bo, bd, va, e1, e2, t, u, v);
+						if (FLAGS & PT_F_STATS) {
+							const int here = (sub16 < count - base ? 1 : 0) + (sub16 + 16 < count - base ? 1 : 0);
+							act += here; dg2 += here;
+						}
+					}
+					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128; dg3 += 128; } }
+					// fold in triangle order: slot 0 holds triangles base..base+15, slot 1 base+16..base+31
+#pragma unroll
+					for (int slot = 0; slot < 2; ++slot) {
+						unsigned long long hm = __ballot((hb >> slot) & 1u);
+						const float ts_ = slot ? t.y : t.x, us_ = slot ? u.y : u.x, vs_ = slot ? v.y : v.x;
+						while (hm != 0ull) {
+							// the lowest remaining hit of every quarter is handled in this iteration
+							const uint32_t g0 = (uint32_t)hm & 0xffffu, g1 = (uint32_t)(hm >> 16) & 0xffffu;
+							const uint32_t g2 = (uint32_t)(hm >> 32) & 0xffffu, g3 = (uint32_t)(hm >> 48) & 0xffffu;
+							const int w0 = g0 ? (int)__ffs((int)g0) - 1 : 0, w1 = g1 ? (int)__ffs((int)g1) - 1 : 0;
+							const int w2 = g2 ? (int)__ffs((int)g2) - 1 : 0, w3 = g3 ? (int)__ffs((int)g3) - 1 : 0;
+							const int wq = my_quarter == 0 ? w0 : my_quarter == 1 ? w1 : my_quarter == 2 ? w2 : w3;
+							const uint32_t gq = my_quarter == 0 ? g0 : my_quarter == 1 ? g1 : my_quarter == 2 ? g2 : g3;
+							const int w = my_quarter * 16 + wq;
+							const float tt = __shfl(ts_, w, 64), uu = __shfl(us_, w, 64), vv = __shfl(vs_, w, 64);
+							if (owner && gq != 0u) {
+								ts.intersects = true;
+								if (tt < ts.tmin) { ts.tmin = tt; ts.tri = leaf_first + base + slot * 16 + wq; ts.bu = uu; ts.bv = vv; }
+							}
+							unsigned long long clr = 0ull;
+							if (g0) clr |= 1ull << w0;
+							if (g1) clr |= 1ull << (16 + w1);
+							if (g2) clr |= 1ull << (32 + w2);
+							if (g3) clr |= 1ull << (48 + w3);
+							hm &= ~clr;
+						}
+					}
+				}
+			}
+		} else
 		if (FLAT == 2) {
 			// Two steps (four owners) in flight: the broadcasts and triangle loads of step B are issued
 			// before step A is computed, so a wave has two independent memory round trips outstanding

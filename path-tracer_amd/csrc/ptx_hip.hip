@@ -248,6 +248,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	std::vector<DevObject> objs((size_t)d->num_objects);
 	std::vector<float4> nodes, geom, shade, mats;
 	nodes.reserve((size_t)d->num_nodes * 4);
+	std::vector<float4> pairs;   // tri_pair blocks (pt_scene.h)
 	geom.reserve((size_t)d->num_leaf_tris * 3);
 	shade.reserve((size_t)d->num_leaf_tris * 4);
 	int scene_max_depth = 0;
@@ -331,6 +332,20 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 					shade.push_back(make_float4(t.tb[1], t.tc[0], t.tc[1], as_float(o.first_material + t.material)));
 				}
 				rec[3] = make_float4(as_float(-1), as_float(-1), as_float(first_dev), as_float(nd.num_tris));
+				// the same run again as pair-interleaved blocks of 32 slots for the cooperative kernel
+				const int block_first = (int)(pairs.size() / PT_PAIR_BLOCK_F4);
+				const int nblocks = (nd.num_tris + 31) / 32;
+				pairs.resize(pairs.size() + (size_t)nblocks * PT_PAIR_BLOCK_F4, make_float4(0, 0, 0, 0));
+				for (int k = 0; k < nd.num_tris; ++k) {
+					const PtxTriangle& t = d->triangles[o.first_triangle + d->leaf_tris[o.first_leaf_tri + nd.first_tri + k]];
+					const float comp[9] = {t.a[0], t.a[1], t.a[2], t.e1[0], t.e1[1], t.e1[2], t.e2[0], t.e2[1], t.e2[2]};
+					const int b = k / 32, r = k % 32, pr = r % 16, hi = r / 16;
+					for (int c = 0; c < 9; ++c) {
+						float4& q = pairs[(size_t)(block_first + b) * PT_PAIR_BLOCK_F4 + (size_t)(c / 2) * 16 + pr];
+						(&q.x)[(c % 2) * 2 + hi] = comp[c];
+					}
+				}
+				rec[0] = make_float4(as_float(block_first), 0.0f, 0.0f, 0.0f);
 			} else {
 				float l[6] = {0, 0, 0, 0, 0, 0}, r[6] = {0, 0, 0, 0, 0, 0};
 				if (nd.left != -1) {
@@ -385,6 +400,8 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 		UP(soa, tri_soa)
 		s->dev.num_tris = (int)nt;
 	}
+	if (pairs.empty()) pairs.push_back(make_float4(0, 0, 0, 0));
+	UP(pairs, tri_pair)
 	UP(shade, tri_shade)
 	UP(mats, materials)
 #undef UP
@@ -567,21 +584,25 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 #define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
 #define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
 				// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
-				// descent threshold, branch-free triangle test>. PTX_TRAV_VARIANT / ptx_ctx_tune select the
-				// earlier designs for A/B runs (tools/sweep.sh); measured on the bench workload (Mrays/s):
-				//   0: 1290   1: 700 (one ray per lane, static queue split)   2: 755 (same, dynamic chunks)
-				//   3: 940 (cooperative, descent waits for every lane)        4: 1190 (cooperative, early-exit test)
+				// descent threshold, leaf mode>; leaf mode 3 = four leaves per step, two triangles per lane in
+				// packed FP32; 1 = two leaves per step, branch-free test; 0 = same with the early-exit test;
+				// 2 = mode 1 with two steps' loads in flight. PTX_TRAV_VARIANT / ptx_ctx_tune select the earlier
+				// designs for A/B runs (tools/sweep.sh); measured on the bench workload, 64-sample passes (Mrays/s):
+				//   0: 1810   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+				//   3: descent waits for every lane (1350)   4: early-exit test   5: two steps in flight (slower)
+				//   6: two leaves per step, scalar FP32 (1690)
 				if (collect_stats) {
 					if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
-					else COOP(PT_F_STATS, 4, 64, 32, 1);
+					else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
+					else COOP(PT_F_STATS, 4, 64, 32, 3);
 				} else switch (ctx->trav_variant) {
 					case 1: TRAV(0, 1, 3, 0); break;
 					case 2: TRAV(0, 1, 3, 64); break;
-					case 3: COOP(0, 3, 32, 0, 1); break;
+					case 3: COOP(0, 4, 64, 0, 3); break;
 					case 4: COOP(0, 3, 32, 32, 0); break;
 					case 5: COOP(0, 3, 32, 32, 2); break;
-					case 6: COOP(0, 3, 32, 32, 1); break;
-					default: COOP(0, 7, 64, 32, 1); break;
+					case 6: COOP(0, 7, 64, 32, 1); break;
+					default: COOP(0, 4, 64, 32, 3); break;
 				}
 #undef TRAV
 #undef COOP

@@ -1,8 +1,9 @@
-# extra SQ passes for the traversal kernel (instruction mix and wait reasons)
+# SQ instruction-mix passes for the traversal kernel; usage: bash tools/pmc_passes.sh <variant> <outdir-tag>
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/pmc_mix
-mkdir -p $O
-B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
-timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/a -- $B > $O/a.log 2>&1; echo a=$?
-timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/b -- $B > $O/b.log 2>&1; echo b=$?
-timeout -s KILL 120 rocprofv3 --pmc SQ_INST_CYCLES_SALU SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAVES SQ_IFETCH SQ_INSTS_BRANCH --output-format csv -d $O/c -- $B > $O/c.log 2>&1; echo c=$?
+export PTX_TRAV_VARIANT=${1:-0}
+O=gpurun_out/pmc_mix_${2:-v0}
+rm -rf $O; mkdir -p $O
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/a -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/a.log 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/b -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/b.log 2>&1 || exit 2
+timeout -s KILL 120 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $O/c -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/c.log 2>&1 || exit 3
+echo done $1
