@@ -100,28 +100,40 @@ static int env_int(const char* name, int dflt) {
 	return e ? atoi(e) : dflt;
 }
 
+struct Tuning {
+	int wf_batch, trav_variant, trav_blocks_per_cu;
+	bool force_megakernel;
+};
+
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// defaults: the environment, else the values measured best on the bench workload
+static Tuning tuning_defaults() {
+	Tuning t;
+	// samples per pass: large queues amortise the ramp/tail of the persistent traversal launches
+	// (8 -> 64: 1274 -> 1601 Mrays/s); costs 64 B x 64 x pixels of path state
+	t.wf_batch = clampi(env_int("PTX_WF_BATCH", 64), 1, 64);
+	t.force_megakernel = env_int("PTX_MEGAKERNEL", 0) != 0;
+	t.trav_variant = env_int("PTX_TRAV_VARIANT", 0);
+	t.trav_blocks_per_cu = clampi(env_int("PTX_TRAV_BLOCKS", 16), 1, 64);
+	return t;
+}
+
 static void tune_defaults(PtxCtx* c) {
-	c->wf_batch = env_int("PTX_WF_BATCH", 64);   // samples per pass: large queues amortise the ramp/tail of the persistent
-	                                              // traversal launches (8 -> 64: 1274 -> 1601 Mrays/s); 64 B x 64 x pixels of path state
-	if (c->wf_batch < 1) c->wf_batch = 1;
-	if (c->wf_batch > 64) c->wf_batch = 64;
-	c->force_megakernel = env_int("PTX_MEGAKERNEL", 0) != 0;
-	c->trav_variant = env_int("PTX_TRAV_VARIANT", 0);
-	c->trav_blocks_per_cu = env_int("PTX_TRAV_BLOCKS", 16);
-	if (c->trav_blocks_per_cu < 1) c->trav_blocks_per_cu = 1;
+	const Tuning t = tuning_defaults();
+	c->wf_batch = t.wf_batch;
+	c->force_megakernel = t.force_megakernel;
+	c->trav_variant = t.trav_variant;
+	c->trav_blocks_per_cu = t.trav_blocks_per_cu;
 }
 
 extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	if (!ctx || !key) return fail(PTX_E_INVALID, "ptx_ctx_tune: NULL argument");
-	PtxCtx saved = *ctx;
-	tune_defaults(ctx);
-	const int d_batch = ctx->wf_batch, d_var = ctx->trav_variant, d_blocks = ctx->trav_blocks_per_cu;
-	const bool d_mega = ctx->force_megakernel;
-	*ctx = saved;
-	if (!strcmp(key, "trav_variant")) ctx->trav_variant = value < 0 ? d_var : value;
-	else if (!strcmp(key, "trav_blocks")) ctx->trav_blocks_per_cu = value < 0 ? d_blocks : (value < 1 ? 1 : (value > 64 ? 64 : value));
-	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d_batch : (value < 1 ? 1 : (value > 64 ? 64 : value));
-	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d_mega : value != 0;
+	const Tuning d = tuning_defaults();
+	if (!strcmp(key, "trav_variant")) ctx->trav_variant = value < 0 ? d.trav_variant : value;
+	else if (!strcmp(key, "trav_blocks")) ctx->trav_blocks_per_cu = value < 0 ? d.trav_blocks_per_cu : clampi(value, 1, 64);
+	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d.wf_batch : clampi(value, 1, 64);
+	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d.force_megakernel : value != 0;
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
 	return PTX_OK;
 }
@@ -546,7 +558,15 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	int batch = ctx->wf_batch;
 	while (batch > 1 && npt * (size_t)batch > ((size_t)1 << 27)) batch >>= 1;
 	if (batch > num_samples) batch = num_samples;
-	rc = wf_ensure(ctx, (npt * (size_t)batch + WF_ROUNDS * PT_BLOCK), npix * (size_t)batch, scene->num_big);
+	// 100 B of state per path: if the device cannot hold the preferred batch (other tenants, huge frames),
+	// halve it rather than fail; the result does not depend on the batch size
+	for (;;) {
+		rc = wf_ensure(ctx, (npt * (size_t)batch + WF_ROUNDS * PT_BLOCK), npix * (size_t)batch, scene->num_big);
+		if (rc == PTX_OK || batch == 1) break;
+		wf_free(ctx);
+		(void)hipGetLastError();   // clear the sticky out-of-memory status
+		batch >>= 1;
+	}
 	if (rc != PTX_OK) return rc;
 	const int cus = 256;
 	const int maxb = ctx->cam.max_bounces;
