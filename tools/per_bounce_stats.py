@@ -18,5 +18,5 @@ for maxb in range(1, 6):
     cur = d if prev is None else {k: d[k] - prev[k] for k in d}
     r = max(1, cur["trav_rays"])
     print(f"bounce {maxb-1}: trav_rays {cur['trav_rays']:>9} inner/ray {cur['trav_inner']/r:6.1f} tri/ray {cur['trav_tri']/r:6.1f} leaf/ray {cur['trav_leaf']/r:5.1f} "
-          f"step-eff {cur['lane_steps_active']/max(1,cur['lane_steps_total']):.3f} diag0/1 {cur['diag0']/max(1,cur['diag1']):.3f} diag2/3 {cur['diag2']/max(1,cur['diag3']):.3f}", flush=True)
+          f"step-eff {cur['lane_steps_active']/max(1,cur['lane_steps_total']):.3f} diag0/1 {cur['diag0']/max(1,cur['diag1']):.3f} diag2/3 {cur['diag2']/max(1,cur['diag3']):.3f} raw diag {cur['diag0']:.4g} {cur['diag1']:.4g} {cur['diag2']:.4g} {cur['diag3']:.4g}", flush=True)
     prev = d
