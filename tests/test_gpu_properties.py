@@ -122,3 +122,29 @@ def test_errors_are_reported_not_swallowed(pt, ctx):
     gpuops.render_init(ctx, cam)   # context still usable afterwards
     acc, _ = gpuops.render(ctx, scene, cam, 0, 1, 0)
     assert acc.max() > 0
+
+
+@pytest.mark.parametrize("name", ["geoms", "example"])
+def test_converged_image_within_rmse_and_luminance_tolerance(pt, orc, ctx, name):
+    """north_star's second correctness check, SURVEY.md 8(c) G5: a converged GPU image with its OWN seed
+    against oracle images with two other seeds, on linear radiance clamped to [0, 1]:
+        RMSE(gpu, oracle_A) <= 1.25 x RMSE(oracle_A, oracle_B)   and   mean luminance within 1 %.
+    (Same-seed images are bit-identical, tested elsewhere; this one catches a biased or correlated sampler.)"""
+    spp = 1024
+    desc, cam = pt.load_scene(name, width=128, height=96)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+
+    def img(acc):
+        return np.clip(acc[:, :3].astype(np.float64) / spp, 0.0, 1.0)
+
+    a = img(orc.render(desc, cam, 0, spp, 101, nthreads=16)[0])
+    b = img(orc.render(desc, cam, 0, spp, 202, nthreads=16)[0])
+    g = img(gpuops.render(ctx, scene, cam, 0, spp, 303)[0])
+    rmse = lambda x, y: float(np.sqrt(np.mean((x - y) ** 2)))
+    noise = rmse(a, b)
+    assert noise > 0
+    assert rmse(g, a) <= 1.25 * noise, f"{name}: RMSE(gpu, A) {rmse(g, a):.5f} vs noise floor {noise:.5f}"
+    assert rmse(g, b) <= 1.25 * noise
+    lum = lambda x: float((x @ np.array([0.2126, 0.7152, 0.0722])).mean())
+    assert abs(lum(g) - lum(a)) <= 0.01 * lum(a), f"{name}: luminance {lum(g):.5f} vs {lum(a):.5f}"
