@@ -173,3 +173,36 @@ def test_png_writer_roundtrip(pt, tmp_path):
     assert pt.host().pth_write_png(p, 17, 13, 3, img.ctypes.data_as(C.POINTER(C.c_ubyte)), 1) == 0
     back = np.asarray(Image.open(p.decode()))
     assert np.array_equal(back, img[:, ::-1])  # mirror_h = what the reference's viewer shows
+
+
+def test_obj_reader_features(pt, tmp_path):
+    """OBJ features beyond the shipped scenes - negative (relative) indices, `g` groups,
+    several `usemtl` runs in one object, v//vn and v/vt/vn corners, a quad, and the `mtllib` fallback to
+    <obj stem>.mtl when the named library does not exist. Primitive ids follow file order."""
+    (tmp_path / "m.mtl").write_text("newmtl red.diff\nKd 1 0 0\nnewmtl glow.lumi\nKd 1 1 1\nKe 3 3 3\nnewmtl mirror.spec\nKd 0.5 0.5 0.5\nNs 500\nd 0.7\n")
+    (tmp_path / "m.obj").write_text(
+        "mtllib does_not_exist.mtl\n"
+        "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 1 1\n"
+        "g first\nusemtl red.diff\nf 1//1 2//1 3//1\n"
+        "usemtl glow.lumi\nf -4/1/1 -3/2/1 -2/3/1 -1/1/1\n"          # quad with relative indices -> 2 triangles
+        "v 0 0 1\nv 1 0 1\nv 0 1 1\n"
+        "g second\nusemtl mirror.spec\nf -3 -2 -1\n")
+    (tmp_path / "s.json").write_text(
+        '{"camera": {"pixelWidth": 8, "pixelHeight": 8, "direction": [0,0,-1], "up": [0,1,0], "position": [0.5,0.5,3],'
+        ' "screenDist": 1, "screenHeight": 1}, "objects": [{"type": "mesh", "render": true, "src": "%s"}]}' % (tmp_path / "m.obj"))
+    H = pt.host()
+    H.pth_set_device_upload(0)
+    assert H.pth_scene_load(str(tmp_path / "s.json").encode(), 0, 0, -1, -1, -1, -1) == 0, H.pth_last_error()
+    d = H.pth_scene_desc().contents
+    assert d.num_objects == 1 and d.num_triangles == 4
+    mats = [d.materials[i] for i in range(d.num_materials)]
+    tri = [d.triangles[i] for i in range(4)]
+    # triangle 0: red diffuse; 1-2: the quad, luminescent, fan (0,1,2), (0,2,3); 3: mirror from the later vertices
+    assert mats[tri[0].material].type == 1 and tuple(mats[tri[0].material].color) == (1.0, 0.0, 0.0)
+    assert mats[tri[1].material].type == 0 and mats[tri[2].material].type == 0 and tuple(mats[tri[1].material].emittance) == (3.0, 3.0, 3.0)
+    assert mats[tri[3].material].type == 2 and mats[tri[3].material].sharpness == 0.5 and abs(mats[tri[3].material].reflect_factor - 0.7) < 1e-7
+    abc = np.ctypeslib.as_array(H.pth_scene_tri_abc(), shape=(4, 9))
+    assert abc[1].tolist() == [0, 0, 0, 1, 0, 0, 1, 1, 0] and abc[2].tolist() == [0, 0, 0, 1, 1, 0, 0, 1, 0]
+    assert abc[3].tolist() == [0, 0, 1, 1, 0, 1, 0, 1, 1]
+    assert tuple(tri[1].tb) == (1.0, 0.0) and tuple(tri[2].tc) == (0.0, 0.0)
+    assert tuple(tri[0].na) == (0.0, 0.0, 1.0)
