@@ -148,3 +148,55 @@ def test_converged_image_within_rmse_and_luminance_tolerance(pt, orc, ctx, name)
     assert rmse(g, b) <= 1.25 * noise
     lum = lambda x: float((x @ np.array([0.2126, 0.7152, 0.0722])).mean())
     assert abs(lum(g) - lum(a)) <= 0.01 * lum(a), f"{name}: luminance {lum(g):.5f} vs {lum(a):.5f}"
+
+
+def test_fat_leaves_match_oracle(pt, orc, ctx, tmp_path):
+    """Leaves far beyond 32 triangles (the builder keeps a node whole when its 'left' list has <= 16
+    entries, e.g. equal centroids): a flat 32x32 sheet gives two leaves of 1024 triangles, a stack of 100
+    identical triangles one leaf of 100. The cooperative kernel walks such runs in several 32-slot blocks;
+    hits, ties (identical triangles: the first must win) and counters must equal the oracle's."""
+    lines = ["mtllib fat.mtl", "usemtl white.diff"]
+    g = 32
+    for z in range(g + 1):
+        for x in range(g + 1):
+            lines.append(f"v {x - g / 2} 0 {z - g / 2}")
+    vid = lambda x, z: z * (g + 1) + x + 1
+    for z in range(g):
+        for x in range(g):
+            lines.append(f"f {vid(x, z)} {vid(x + 1, z + 1)} {vid(x + 1, z)}")
+            lines.append(f"f {vid(x, z)} {vid(x, z + 1)} {vid(x + 1, z + 1)}")
+    (tmp_path / "fat.obj").write_text("\n".join(lines) + "\n")
+    (tmp_path / "fat.mtl").write_text("newmtl white.diff\nKd 0.8 0.8 0.8\nnewmtl mirror.spec\nKd 0.9 0.9 0.9\nNs 900\nd 0.8\n")
+    dup = ["mtllib fat.mtl", "usemtl mirror.spec", "v -3 0.5 -3", "v 3 0.5 -3", "v 0 4 -3"] + ["f 1 2 3"] * 100
+    (tmp_path / "dup.obj").write_text("\n".join(dup) + "\n")
+    (tmp_path / "s.json").write_text(
+        '{"camera": {"pixelWidth": 96, "pixelHeight": 64, "direction": [0,-0.5,-1], "up": [0,1,0], "position": [0,6,12],'
+        ' "screenDist": 1.5, "screenHeight": 2}, "objects": ['
+        '{"type": "sphere", "render": true, "radius": 4, "position": [0, 12, 0], "material": {"type": "lumi", "Kd": [1], "Ke": [6]}},'
+        '{"type": "mesh", "render": true, "src": "%s"}, {"type": "mesh", "render": true, "src": "%s"}]}'
+        % (tmp_path / "fat.obj", tmp_path / "dup.obj"))
+    desc, cam = pt.load_scene(str(tmp_path / "s.json"))
+    d = desc.contents
+    leaf_sizes = sorted(d.nodes[i].num_tris for i in range(d.num_nodes) if d.nodes[i].left == -1 and d.nodes[i].right == -1)
+    assert leaf_sizes[-1] >= 1024 and 100 in leaf_sizes
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 0, 4, 6)
+    try:
+        for variant in (0, 1, 6):
+            _tune(pt, ctx, b"trav_variant", variant)
+            acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 4, 6, stats=True)
+            assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32)), f"variant {variant}"
+            for k in ("rays", "n_inner", "n_tri", "n_leaf", "hit_mesh", "trav_rays", "trav_tri"):
+                assert getattr(st_o, k) == getattr(st_g, k), (variant, k)
+            acc_f, _ = gpuops.render(ctx, scene, cam, 0, 4, 6)
+            assert np.array_equal(acc_o.view(np.uint32), acc_f.view(np.uint32)), f"variant {variant}, timing kernels"
+    finally:
+        _tune(pt, ctx, b"trav_variant", -1)
+    assert st_o.hit_mesh > 0 and acc_o[:, :3].max() > 0
+    # the mirror stack is hit, and its hits name the FIRST of the 100 identical triangles
+    o, dd = orc.generate_rays(cam, -1, 0)
+    ho, hg = orc.trace(desc, o, dd, 2), gpuops.trace(ctx, scene, o, dd, 2)
+    assert (ho["hit"] == 1).sum() > 50 and set(ho["prim"][ho["hit"] == 1]) == {0}
+    for k in ho:
+        assert np.array_equal(ho[k], hg[k]), k
