@@ -200,3 +200,57 @@ def test_fat_leaves_match_oracle(pt, orc, ctx, tmp_path):
     assert (ho["hit"] == 1).sum() > 50 and set(ho["prim"][ho["hit"] == 1]) == {0}
     for k in ho:
         assert np.array_equal(ho[k], hg[k]), k
+
+
+def _many_mesh_scene(tmp_path, n_meshes, tris_per_mesh=48):
+    """n_meshes multi-node meshes (random small triangles, > 33 each so the KD build splits them), partly
+    overlapping in space so that closest-hit decisions cross object boundaries, plus a light."""
+    rng = np.random.default_rng(17)
+    (tmp_path / "m.mtl").write_text("newmtl a.diff\nKd 0.7 0.6 0.5\nnewmtl b.spec\nKd 0.9 0.9 0.9\nNs 700\nd 0.5\n")
+    objs = ['{"type": "sphere", "render": true, "radius": 6, "position": [0, 14, 0], "material": {"type": "lumi", "Kd": [1], "Ke": [5]}}']
+    for m in range(n_meshes):
+        c = rng.normal(0, 1.6, 3)
+        lines = ["mtllib m.mtl", "usemtl " + ("a.diff" if m % 2 else "b.spec")]
+        for t in range(tris_per_mesh):
+            p = c + rng.normal(0, 0.9, 3)
+            for k in range(3):
+                q = p + rng.normal(0, 0.35, 3)
+                lines.append("v %.6f %.6f %.6f" % tuple(q))
+            lines.append(f"f {3 * t + 1} {3 * t + 2} {3 * t + 3}")
+        (tmp_path / f"m{m}.obj").write_text("\n".join(lines) + "\n")
+        objs.append('{"type": "mesh", "render": true, "src": "%s"}' % (tmp_path / f"m{m}.obj"))
+    (tmp_path / "s.json").write_text(
+        '{"camera": {"pixelWidth": 80, "pixelHeight": 60, "direction": [0,0,-1], "up": [0,1,0], "position": [0,0,9],'
+        ' "screenDist": 1.5, "screenHeight": 2}, "objects": [%s]}' % ",".join(objs))
+    return str(tmp_path / "s.json")
+
+
+@pytest.mark.parametrize("n_meshes", [3, 31])
+def test_several_multi_node_meshes_match_oracle(pt, orc, ctx, tmp_path, n_meshes):
+    """One traversal queue per multi-node mesh, traversed one after the other into the same closest-hit
+    record: the outcome must be the reference's in-order object loop (strict '<', lower object index wins
+    ties). 31 is the most the wavefront pipeline queues (the object cap is 32, one is the light)."""
+    desc, cam = pt.load_scene(_many_mesh_scene(tmp_path, n_meshes))
+    d = desc.contents
+    assert d.num_objects == n_meshes + 1
+    assert all(d.objects[i].num_nodes > 1 for i in range(1, d.num_objects))
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 0, 3, 8)
+    acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 3, 8, stats=True)
+    assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32))
+    for k in ("rays", "n_inner", "n_box", "n_tri", "n_leaf", "hit_mesh", "hit_sphere", "trav_rays", "trav_inner", "trav_tri"):
+        assert getattr(st_o, k) == getattr(st_g, k), k
+    acc_f, _ = gpuops.render(ctx, scene, cam, 0, 3, 8)
+    assert np.array_equal(acc_o.view(np.uint32), acc_f.view(np.uint32))
+    try:
+        _tune(pt, ctx, b"megakernel", 1)
+        acc_m, _ = gpuops.render(ctx, scene, cam, 0, 3, 8)
+        assert np.array_equal(acc_o.view(np.uint32), acc_m.view(np.uint32))
+    finally:
+        _tune(pt, ctx, b"megakernel", -1)
+    assert st_o.hit_mesh > 100
+    o, dd = orc.generate_rays(cam, -1, 0)
+    ho, hg = orc.trace(desc, o, dd), gpuops.trace(ctx, scene, o, dd)
+    for k in ho:
+        assert np.array_equal(ho[k], hg[k]), k
