@@ -117,8 +117,9 @@ typedef struct PtxSceneDesc {
 
 /* Result of one rayIntersectsScene-equivalent query (parity entry point). */
 typedef struct PtxHit {
-	int32_t hit;            /* 0/1 */
-	int32_t object;         /* index of the closest object, -1 if none */
+	int32_t hit;            /* 0/1: the reference's return value "some intersection test succeeded" */
+	int32_t object;         /* index of the closest object, -1 if none (possible with hit = 1 when every success lies at an
+	                         * infinite distance, e.g. unnormalised 1e18 directions; point/normal/bary are then zero) */
 	int32_t prim;           /* ORIGINAL triangle index inside that object, -1 for spheres/miss */
 	uint32_t t_bits;        /* bit pattern of length(ipoint - origin) of the closest hit */
 	uint32_t leaf_hash;     /* FNV-1a over (object, leaf node idx) in visit order, all meshes */

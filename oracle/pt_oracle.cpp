@@ -717,7 +717,7 @@ extern "C" int orc_trace_rays(const PtxSceneDesc* scene, int n, const float* ori
 		memcpy(&h.t_bits, &ii.dist, 4);
 		h.leaf_hash = cnt.leaf_hash;
 		h.n_inner = (uint32_t)cnt.n_inner; h.n_box = (uint32_t)cnt.n_box; h.n_tri = (uint32_t)cnt.n_tri; h.n_leaf = (uint32_t)cnt.n_leaf;
-		if (hit) {
+		if (hit && ii.iobj_index >= 0) { // no object recorded (all successes at infinite distance): zeros, not stale memory
 			h.point[0] = ii.ipoint.x; h.point[1] = ii.ipoint.y; h.point[2] = ii.ipoint.z;
 			h.normal[0] = ii.normal.x; h.normal[1] = ii.normal.y; h.normal[2] = ii.normal.z;
 			h.bary[0] = ii.bary.x; h.bary[1] = ii.bary.y; h.bary[2] = ii.bary.z;

@@ -191,7 +191,10 @@ __global__ __launch_bounds__(PT_BLOCK) void trace_kernel(DevScene sc, int n, con
 	h.t_bits = __float_as_uint(hi.dist);
 	h.leaf_hash = cnt.leaf_hash;
 	h.n_inner = cnt.n_inner; h.n_box = cnt.n_box; h.n_tri = cnt.n_tri; h.n_leaf = cnt.n_leaf;
-	if (hit) {
+	// "hit" is the reference's return value ("some test succeeded"); when every success sat at an infinite
+	// distance no object was recorded (object = -1) and the reference leaves its IntersectInfo untouched:
+	// the record then carries zeros rather than stale memory
+	if (hit && hi.object >= 0) {
 		h.point[0] = hi.point.x; h.point[1] = hi.point.y; h.point[2] = hi.point.z;
 		h.normal[0] = hi.normal.x; h.normal[1] = hi.normal.y; h.normal[2] = hi.normal.z;
 		h.bary[0] = hi.bary.x; h.bary[1] = hi.bary.y; h.bary[2] = hi.bary.z;

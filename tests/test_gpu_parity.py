@@ -169,3 +169,27 @@ def test_fast_reciprocal_is_exact(pt, ctx):
     # outside the range the shortcut is wrong, which is why pt_rcp_det falls back to the division there
     pt.check(pt.lib().ptx_selftest_rcp(ctx, 2.0 ** 126 * 1.0001, 3.0e38, C.byref(c), C.byref(m), C.byref(f)))
     assert m.value > 0
+
+
+@pytest.mark.parametrize("name", ["teapot", "geoms"])
+def test_degenerate_rays_bit_exact(pt, orc, ctx, name):
+    """Rays the render path never makes but the entry point accepts: zero and axis-parallel directions
+    (inverse = +-inf, 0 * inf = NaN in the slab test), unnormalised tiny / huge directions, origins at 1e30,
+    NaN origins, infinite directions, origins on box planes. Every field must equal the oracle's."""
+    desc, cam = pt.load_scene(name, width=32, height=24)
+    scene = pt.host().pth_scene_device()
+    rng = np.random.default_rng(4)
+    n = 4096
+    o = rng.normal(0, 3, (n, 3)).astype(np.float32)
+    d = rng.normal(0, 1, (n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[0:64] = 0
+    d[64:128, 0] = 0; d[128:192, 1] = 0; d[192:256, 2] = 0; d[256:320, :2] = 0
+    d[320:384] *= 1e-20; d[384:448] *= 1e18
+    o[448:512] = 1e30; o[512:520] = np.nan; d[520:528] = np.inf
+    o[528:600] = 0
+    ho, hg = orc.trace(desc, o, d), gpuops.trace(ctx, scene, o, d)
+    for k in ho:
+        bad = np.nonzero((ho[k] != hg[k]).reshape(n, -1).any(axis=1))[0]
+        assert len(bad) == 0, f"{name}: {k} differs for {len(bad)} rays, first {bad[:8]}"
+    assert ((ho["hit"] == 1) & (ho["object"] == 0xFFFFFFFF)).any()   # the hit-without-object case is covered
