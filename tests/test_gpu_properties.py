@@ -254,3 +254,43 @@ def test_several_multi_node_meshes_match_oracle(pt, orc, ctx, tmp_path, n_meshes
     ho, hg = orc.trace(desc, o, dd), gpuops.trace(ctx, scene, o, dd)
     for k in ho:
         assert np.array_equal(ho[k], hg[k]), k
+
+
+def test_camera_change_restarts_like_the_reference(pt, orc, ctx):
+    """reference: src/pathtracing.cu:166-172 + qt/cudarunthread.cpp:24-25 - a camera change regenerates the
+    primary rays and the accumulation restarts at iteration 1. Through the host entry points (runCUDA) and
+    through ptx_render_set_camera directly; both equal an oracle render with the moved camera."""
+    H, L = pt.host(), pt.lib()
+    desc, cam0 = pt.load_scene("geoms", width=64, height=48)
+    scene = H.pth_scene_device()
+    assert H.pth_kernel_init() == 0
+    pbo = np.zeros((64 * 48, 4), np.uint8)
+    pp = pbo.ctypes.data_as(C.POINTER(C.c_ubyte))
+    for it in (1, 2, 3):
+        assert H.pth_run_iteration(it, pp) == it       # returns the iteration it rendered
+    # move and turn the camera the way the GUI does (SceneState setters), then restart at iteration 1
+    H.pth_camera_control(b"h_ang", 25.0)
+    H.pth_camera_control(b"v_ang", -8.0)
+    H.pth_camera_control(b"pos_x", float(np.float32(cam0.position[0]) + np.float32(0.75)))
+    cam1 = pt.PtxCamera()
+    assert H.pth_camera_get(C.byref(cam1)) == 0
+    assert tuple(cam1.direction) != tuple(cam0.direction) and cam1.position[0] != cam0.position[0]
+    assert H.pth_run_iteration(4, pp) == 1            # the caller asked for iteration 4: camera changed -> 1
+    assert H.pth_run_iteration(2, pp) == 2
+    acc = np.empty((64 * 48, 4), np.float32)
+    pt.check(L.ptx_accum_download(ctx, acc.ctypes.data_as(C.POINTER(C.c_float))))
+    ref, _ = orc.render(desc, cam1, 0, 2, 0)
+    assert np.array_equal(acc.view(np.uint32), ref.view(np.uint32))
+    out_o = np.empty((64 * 48, 4), np.uint8)
+    assert orc.lib().orc_tonemap(orc.fptr(ref), 64 * 48, 2, cam1.gamma_corr, out_o.ctypes.data_as(C.POINTER(C.c_ubyte))) == 0
+    assert np.abs(pbo.astype(int) - out_o.astype(int)).max() <= 1      # the "PBO" holds the tone-mapped 2-spp image
+    # the C ABI directly
+    gpuops.render_init(ctx, cam0)
+    gpuops.render(ctx, scene, cam0, 0, 3, 0)
+    pt.check(L.ptx_render_set_camera(ctx, C.byref(cam1)))
+    got, _ = gpuops.render(ctx, scene, cam1, 0, 2, 0)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    bad = pt.PtxCamera()
+    C.memmove(C.byref(bad), C.byref(cam1), C.sizeof(cam1))
+    bad.width = 32
+    assert L.ptx_render_set_camera(ctx, C.byref(bad)) != 0               # resolution must not change
