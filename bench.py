@@ -85,6 +85,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # stdout carries exactly one JSON line: the loader's progress chatter (C stdio) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -228,7 +233,10 @@ def main():
                    "parallelism": f"spp-split x{world}"},
         "roofline": roofline, "cpu_baseline": cpu,
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    C.CDLL(None).fflush(None)
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
