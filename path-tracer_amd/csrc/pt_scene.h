@@ -11,7 +11,11 @@
 //                q3 = int4(left, right, tri_first, tri_count)
 //              L/R = the CHILDREN's boxes, stored in the parent so one record serves both
 //              box tests of an inner step; left/right are scene-global node indices (-1 = none);
-//              tri_first/tri_count address tri_geom/tri_shade (leaves only).
+//              tri_first/tri_count address tri_geom/tri_shade (leaves only). In INNER nodes q3.z/q3.w hold
+//              the two child links again in packed form for the cooperative traversal kernel: >= 0 node
+//              index, -1 none, and for a leaf child with 1..63 triangles 0x80000000 | block << 6 | count
+//              (its triangle run itself: tri_first = 32 * block, every run starts on a multiple of 32), so
+//              the kernel never fetches that leaf's node record.
 //   tri_geom   3 x float4 per triangle (48 B), stored in LEAF ORDER (the KD build partitions
 //              triangles, every triangle is in exactly one leaf, so leaf lists become
 //              contiguous runs and the reference's trg_idxs indirection disappears):

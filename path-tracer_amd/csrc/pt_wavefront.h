@@ -597,8 +597,8 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				const float4 q0 = nodes[4 * curr + 0];
 				const float4 q1 = nodes[4 * curr + 1];
 				const float4 q2 = nodes[4 * curr + 2];
-				const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-				if (left == -1 && right == -1) {
+				if (__float_as_int(q3.x) == -1 && __float_as_int(q3.y) == -1) {
+					// a leaf reached through a plain link (more than 63 triangles, or none)
 					leaf_first = __float_as_int(q3.z);
 					leaf_count = __float_as_int(q3.w);
 					leaf_block = __float_as_int(q0.x);
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 					}
 					state = LEAF;
 				} else {
+					const int left = __float_as_int(q3.z), right = __float_as_int(q3.w);   // packed links: pt_scene.h
 					if (FLAGS & PT_F_STATS) cnt.n_inner++;
 					float left_dist = __builtin_huge_valf(), right_dist = __builtin_huge_valf();
 					bool left_res = false, right_res = false;
@@ -638,6 +639,19 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 						ts.curr = stack[ts.sp * PT_BLOCK];
 					}
 				}
+			}
+			// a link that names a leaf run (0x80000000 | block << 6 | count) is taken up at once: no node fetch
+			if (state == DESCEND && ts.curr < -1) {
+				leaf_block = (int)(((uint32_t)ts.curr & 0x7fffffffu) >> 6);
+				leaf_first = leaf_block << 5;
+				leaf_count = ts.curr & 63;
+				if (FLAGS & PT_F_STATS) {
+					cnt.n_leaf++;
+					cnt.n_tri += (uint32_t)leaf_count;
+					fnv_word(cnt.leaf_hash, (uint32_t)obj_index);
+					fnv_word(cnt.leaf_hash, (uint32_t)__float_as_int(sc.tri_geom[3 * leaf_first + 2].z)); // the leaf's node index
+				}
+				state = LEAF;
 			}
 		}
 
@@ -847,6 +861,18 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				--ts.sp;
 				ts.curr = stack[ts.sp * PT_BLOCK];
 				state = DESCEND;
+				if (ts.curr < -1) {   // the popped link names a leaf run
+					leaf_block = (int)(((uint32_t)ts.curr & 0x7fffffffu) >> 6);
+					leaf_first = leaf_block << 5;
+					leaf_count = ts.curr & 63;
+					if (FLAGS & PT_F_STATS) {
+						cnt.n_leaf++;
+						cnt.n_tri += (uint32_t)leaf_count;
+						fnv_word(cnt.leaf_hash, (uint32_t)obj_index);
+						fnv_word(cnt.leaf_hash, (uint32_t)__float_as_int(sc.tri_geom[3 * leaf_first + 2].z));
+					}
+					state = LEAF;
+				}
 			}
 		}
 	}

@@ -217,6 +217,7 @@ extern "C" int ptx_ctx_destroy(PtxCtx* ctx) {
 // ---- scene upload -----------------------------------------------------------------------------
 
 static inline float as_float(int32_t v) { float f; memcpy(&f, &v, 4); return f; }
+static inline int32_t as_int(float f) { int32_t v; memcpy(&v, &f, 4); return v; }
 
 template <typename T>
 static int upload_vec(PtxCtx* ctx, PtxScene* s, const std::vector<T>& v, const T** out) {
@@ -343,9 +344,16 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 					shade.push_back(make_float4(t.nc[0], t.nc[1], t.nc[2], t.tb[0]));
 					shade.push_back(make_float4(t.tb[1], t.tc[0], t.tc[1], as_float(o.first_material + t.material)));
 				}
+				// every leaf run starts on a multiple of 32 (zero records in between: never indexed, never hit),
+				// so that run and tri_pair block share one number: first = 32 * block
+				while ((geom.size() / 3) % 32 != 0) {
+					for (int z = 0; z < 3; ++z) geom.push_back(make_float4(0, 0, 0, 0));
+					for (int z = 0; z < 4; ++z) shade.push_back(make_float4(0, 0, 0, 0));
+				}
 				rec[3] = make_float4(as_float(-1), as_float(-1), as_float(first_dev), as_float(nd.num_tris));
 				// the same run again as pair-interleaved blocks of 32 slots for the cooperative kernel
 				const int block_first = (int)(pairs.size() / PT_PAIR_BLOCK_F4);
+				if (block_first * 32 != first_dev) return fail(PTX_E_INVALID, "internal: leaf run %d not aligned with block %d", first_dev, block_first);
 				const int nblocks = (nd.num_tris + 31) / 32;
 				pairs.resize(pairs.size() + (size_t)nblocks * PT_PAIR_BLOCK_F4, make_float4(0, 0, 0, 0));
 				for (int k = 0; k < nd.num_tris; ++k) {
@@ -373,9 +381,28 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 				rec[0] = make_float4(l[0], l[1], l[2], l[3]);
 				rec[1] = make_float4(l[4], l[5], r[0], r[1]);
 				rec[2] = make_float4(r[2], r[3], r[4], r[5]);
+				// .x/.y: child node indices; .z/.w: the same links in packed form, filled in below
 				rec[3] = make_float4(as_float(nd.left == -1 ? -1 : base + nd.left), as_float(nd.right == -1 ? -1 : base + nd.right),
-				                     as_float(0), as_float(0));
+				                     as_float(-1), as_float(-1));
 			}
+		}
+		// Packed links (pt_scene.h): a child that is a leaf with 1..63 triangles is named by its triangle run,
+		// 0x80000000 | block << 6 | count, so the cooperative traversal never fetches the leaf's node record.
+		for (int k = 0; k < o.num_nodes; ++k) {
+			float4& q3 = nodes[(size_t)(base + k) * 4 + 3];
+			const int32_t links[2] = {as_int(q3.x), as_int(q3.y)};
+			if (links[0] == -1 && links[1] == -1) continue; // leaf
+			int32_t enc[2];
+			for (int c = 0; c < 2; ++c) {
+				enc[c] = links[c];
+				if (links[c] < 0) continue;
+				const float4 c3 = nodes[(size_t)links[c] * 4 + 3];
+				const int32_t cf = as_int(c3.z), cc = as_int(c3.w);
+				if (as_int(c3.x) == -1 && as_int(c3.y) == -1 && cc >= 1 && cc <= 63 && (cf >> 5) < (1 << 24))
+					enc[c] = (int32_t)(0x80000000u | ((uint32_t)(cf >> 5) << 6) | (uint32_t)cc);
+			}
+			q3.z = as_float(enc[0]);
+			q3.w = as_float(enc[1]);
 		}
 		if (depth_max > scene_max_depth) scene_max_depth = depth_max;
 		if (!(on[0].left == -1 && on[0].right == -1)) {
