@@ -129,13 +129,13 @@ PT_DEV v2f rcp_det_x2(v2f a) {
 	r = __builtin_elementwise_fma(e, r, r);
 	return r;
 }
-PT_DEV uint32_t tri_test_flat_x2(f3 o, f3 dir, const f3x2& va, const f3x2& e1, const f3x2& e2, v2f& res_t, v2f& ru, v2f& rv) {
-	f3x2 d, s;
-	d.x = splat2(dir.x); d.y = splat2(dir.y); d.z = splat2(dir.z);
+// o2 / d: the ray's origin and direction with each component in both halves of a pair
+PT_DEV uint32_t tri_test_flat_x2p(const f3x2& o2, const f3x2& d, const f3x2& va, const f3x2& e1, const f3x2& e2, v2f& res_t, v2f& ru, v2f& rv) {
+	f3x2 s;
 	const f3x2 h = cross3x2(d, e2);
 	const v2f a = dot3x2(e1, h);
 	const v2f f = rcp_det_x2(a);
-	s.x = splat2(o.x) - va.x; s.y = splat2(o.y) - va.y; s.z = splat2(o.z) - va.z;
+	s.x = o2.x - va.x; s.y = o2.y - va.y; s.z = o2.z - va.z;
 	const v2f u = f * dot3x2(s, h);
 	const f3x2 q = cross3x2(s, e1);
 	const v2f v = f * dot3x2(d, q);
@@ -151,6 +151,12 @@ PT_DEV uint32_t tri_test_flat_x2(f3 o, f3 dir, const f3x2& va, const f3x2& e1, c
 		if ((ok_a & ok_u) & (ok_v & (t[k] > PT_TRI_EPSILON))) bits |= 1u << k;
 	}
 	return bits;
+}
+PT_DEV uint32_t tri_test_flat_x2(f3 o, f3 dir, const f3x2& va, const f3x2& e1, const f3x2& e2, v2f& res_t, v2f& ru, v2f& rv) {
+	f3x2 d, o2;
+	d.x = splat2(dir.x); d.y = splat2(dir.y); d.z = splat2(dir.z);
+	o2.x = splat2(o.x); o2.y = splat2(o.y); o2.z = splat2(o.z);
+	return tri_test_flat_x2p(o2, d, va, e1, e2, res_t, ru, rv);
 }
 
 // reference: src/intersect.cuh:59-83 testSphereIntersection

@@ -488,6 +488,21 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 	if (FLAGS & PT_F_STATS) diag_flush(wp.stats, dg0, dg1, dg2, dg3);
 }
 
+// LDS staging area of leaf mode 4: per wave 64 slots of WF_STAGE_F4 float4, behind the traversal stacks
+#define WF_STAGE_F4 4
+#define WF_STAGE_BYTES ((PT_BLOCK / 64) * 64 * WF_STAGE_F4 * 16)
+
+// Minimum over the 16 lanes of a DPP row, left in every lane of the row: xor 1 and xor 2 inside the
+// quads, then the half-row and row mirrors (the values are already uniform per quad / per half).
+PT_DEV uint32_t row_min_u32(uint32_t x) {
+	uint32_t y;
+	y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0xB1, 0xf, 0xf, false); x = y < x ? y : x;    // quad_perm [1,0,3,2]
+	y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x4E, 0xf, 0xf, false); x = y < x ? y : x;    // quad_perm [2,3,0,1]
+	y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x141, 0xf, 0xf, false); x = y < x ? y : x;   // row_half_mirror
+	y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x140, 0xf, 0xf, false); x = y < x ? y : x;   // row_mirror
+	return x;
+}
+
 // Cooperative variant of the traversal kernel: the DESCENT stays one ray per lane, the LEAVES are
 // tested by the wave together.
 //
@@ -657,6 +672,84 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 
 		// ---- leaves: two owners per step, one per half-wave ----
 		unsigned long long m = __ballot(state == LEAF);
+		if (FLAT == 4) {
+			// Mode 3's step (four owners, one per 16-lane quarter, two triangles per lane in packed FP32)
+			// with the hand-over moved to LDS. Every LEAF lane writes its ray and leaf run ONCE per round
+			// into slot `rank` (its rank among the LEAF lanes) of the wave's staging area; step s serves
+			// slots 4s..4s+3, quarter q reads slot 4s+q (a broadcast read) - no owner search, no per-step
+			// shuffles. The hits of a quarter are reduced with DPP row operations (min t, then the lowest
+			// triangle slot among equal t: the serial loop's "first strictly smaller wins"), the winning
+			// lane writes (t, u, v, slot) back INTO the slot, and the owners pick their results up after
+			// the last step. A slot is 4 float4, the ray components already doubled into the register
+			// pairs the packed test wants: (ox ox oy oy)(oz oz dx dx)(dy dy dz dz)(block, count, key, -);
+			// the result replaces the first word.
+			float4* stage = reinterpret_cast<float4*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * (WF_STAGE_F4 * 64);
+			const int quarter = lane >> 4, sub16 = lane & 15;
+			const float4* __restrict__ pp = sc.tri_pair;
+			const int nleaf = (int)__popcll(m);
+			const int rank = (int)__popcll(m & ((1ull << lane) - 1ull));
+			if (state == LEAF) {
+				float4* sl = stage + WF_STAGE_F4 * rank;
+				sl[0] = make_float4(ray.o.x, ray.o.x, ray.o.y, ray.o.y);
+				sl[1] = make_float4(ray.o.z, ray.o.z, ray.d.x, ray.d.x);
+				sl[2] = make_float4(ray.d.y, ray.d.y, ray.d.z, ray.d.z);
+				sl[3] = make_float4(__int_as_float(leaf_block), __int_as_float(leaf_count), __uint_as_float(0xffffffffu), 0.0f);
+			}
+			__builtin_amdgcn_wave_barrier();
+			for (int s4 = 0; s4 < nleaf; s4 += 4) {
+				const int slot = s4 + quarter;               // <= 63
+				float4* sl = stage + WF_STAGE_F4 * slot;
+				const float4 r0 = sl[0], r1 = sl[1], r2 = sl[2], r3 = sl[3];
+				f3x2 bo, bd;
+				bo.x = (v2f){r0.x, r0.y}; bo.y = (v2f){r0.z, r0.w}; bo.z = (v2f){r1.x, r1.y};
+				bd.x = (v2f){r1.z, r1.w}; bd.y = (v2f){r2.x, r2.y}; bd.z = (v2f){r2.z, r2.w};
+				const int blk = __float_as_int(r3.x);
+				const int count = slot < nleaf ? __float_as_int(r3.y) : 0;   // slots past nleaf hold stale data
+				uint32_t best_k = 0xffffffffu;
+				for (int base = 0; __ballot(base < count) != 0ull; base += 32) {
+					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128; dg3 += 128; } }
+					if (base < count) {   // uniform per quarter (= per DPP row)
+						const float4* bp = pp + ((size_t)(blk + (base >> 5)) * PT_PAIR_BLOCK_F4 + sub16);
+						const float4 c0 = bp[0], c1 = bp[16], c2 = bp[32], c3 = bp[48], c4 = bp[64];
+						f3x2 va, e1, e2;
+						va.x = (v2f){c0.x, c0.y}; va.y = (v2f){c0.z, c0.w}; va.z = (v2f){c1.x, c1.y};
+						e1.x = (v2f){c1.z, c1.w}; e1.y = (v2f){c2.x, c2.y}; e1.z = (v2f){c2.z, c2.w};
+						e2.x = (v2f){c3.x, c3.y}; e2.y = (v2f){c3.z, c3.w}; e2.z = (v2f){c4.x, c4.y};
+						v2f t, u, v;
+						const uint32_t hb = tri_test_flat_x2p(bo, bd, va, e1, e2, t, u, v);
+						if (FLAGS & PT_F_STATS) {
+							const int here = (sub16 < count - base ? 1 : 0) + (sub16 + 16 < count - base ? 1 : 0);
+							act += here; dg2 += here;
+						}
+						if (__ballot(hb != 0u) != 0ull) {
+							// a hit has t > 5e-8, so its bit pattern orders like its value; 0xffffffff = no hit
+							const uint32_t k0 = (hb & 1u) ? __float_as_uint(t.x) : 0xffffffffu;
+							const uint32_t k1 = (hb & 2u) ? __float_as_uint(t.y) : 0xffffffffu;
+							const uint32_t k = row_min_u32(k0 < k1 ? k0 : k1);
+							const uint32_t cand = row_min_u32(k0 == k ? (uint32_t)sub16 : k1 == k ? (uint32_t)sub16 + 16u : 64u);
+							if (k < best_k) {   // strict: an earlier block of the run keeps a tie
+								best_k = k;
+								if ((cand & 15u) == (uint32_t)sub16) {
+									const bool second = cand >= 16u;
+									sl[0] = make_float4(second ? t.y : t.x, second ? u.y : u.x, second ? v.y : v.x, __int_as_float(base + (int)cand));
+									sl[3].z = __uint_as_float(k);
+								}
+							}
+						}
+					}
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (state == LEAF) {
+				const float4* sl = stage + WF_STAGE_F4 * rank;
+				const float4 res = sl[0];
+				const uint32_t k = __float_as_uint(sl[3].z);
+				if (k != 0xffffffffu) {
+					ts.intersects = true;
+					if (res.x < ts.tmin) { ts.tmin = res.x; ts.tri = leaf_first + __float_as_int(res.w); ts.bu = res.y; ts.bv = res.z; }
+				}
+			}
+		} else
 		if (FLAT == 3) {
 			// Four owners per step, one per 16-lane quarter; every lane tests TWO triangles of its owner's run
 			// (slots p and p + 16 of a tri_pair block, pt_scene.h) with packed FP32 arithmetic. Padding

@@ -629,19 +629,24 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				const int obj = scene->big_object[k];
 				prof_mark(ctx, 0);
 #define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
-#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
+#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
 				// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
-				// descent threshold, leaf mode>; leaf mode 3 = four leaves per step, two triangles per lane in
-				// packed FP32; 1 = two leaves per step, branch-free test; 0 = same with the early-exit test;
-				// 2 = mode 1 with two steps' loads in flight. PTX_TRAV_VARIANT / ptx_ctx_tune select the earlier
-				// designs for A/B runs (tools/sweep.sh); measured on the bench workload, 64-sample passes (Mrays/s):
-				//   0: 1810   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+				// descent threshold, leaf mode>. Leaf modes: 4 = four leaves per step, two triangles per lane in
+				// packed FP32, rays handed over through LDS and hits reduced with DPP (needs WF_STAGE_BYTES of
+				// LDS behind the stacks; deeper trees fall back to mode 3); 3 = the same step with the rays
+				// broadcast by shuffles and the hits folded one by one; 1 = two leaves per step, branch-free
+				// scalar test; 0 = same with the early-exit test; 2 = mode 1 with two steps' loads in flight.
+				// PTX_TRAV_VARIANT / ptx_ctx_tune select the earlier designs for A/B runs (tools/sweep.sh);
+				// measured on the bench workload, 64-sample passes (Mrays/s):
+				//   0: 2008   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
 				//   3: descent waits for every lane (1350)   4: early-exit test   5: two steps in flight (slower)
-				//   6: two leaves per step, scalar FP32 (1690)
+				//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
+				const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 				if (collect_stats) {
 					if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
 					else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
-					else COOP(PT_F_STATS, 4, 64, 32, 3);
+					else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
+					else COOP(PT_F_STATS, 4, 64, 32, 4);
 				} else switch (ctx->trav_variant) {
 					case 1: TRAV(0, 1, 3, 0); break;
 					case 2: TRAV(0, 1, 3, 64); break;
@@ -649,7 +654,9 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 					case 4: COOP(0, 3, 32, 32, 0); break;
 					case 5: COOP(0, 3, 32, 32, 2); break;
 					case 6: COOP(0, 7, 64, 32, 1); break;
-					default: COOP(0, 4, 64, 32, 3); break;
+					case 7: COOP(0, 4, 64, 32, 3); break;
+					case 8: if (stage_fits) COOP(0, 4, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
+					default: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
 				}
 #undef TRAV
 #undef COOP
