@@ -492,6 +492,22 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 #define WF_STAGE_F4 4
 #define WF_STAGE_BYTES ((PT_BLOCK / 64) * 64 * WF_STAGE_F4 * 16)
 
+// LDS staging area of leaf mode 5, per wave: 64 ray slots of two float4, 64 64-bit result keys and a list
+// of WF_UNIT_CAP 16-bit work units (owner slot | group << 6)
+#define WF_UNIT_CAP 512
+#define WF_GRP_WAVE_BYTES (64 * 2 * 16 + 64 * 8 + WF_UNIT_CAP * 2)
+#define WF_GRP_BYTES ((PT_BLOCK / 64) * WF_GRP_WAVE_BYTES)
+
+PT_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
+
+// Minimum over the 4 lanes of a quad, left in every lane of the quad
+PT_DEV uint32_t quad_min_u32(uint32_t x) {
+	uint32_t y;
+	y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0xB1, 0xf, 0xf, false); x = y < x ? y : x;    // quad_perm [1,0,3,2]
+	y = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x4E, 0xf, 0xf, false); x = y < x ? y : x;    // quad_perm [2,3,0,1]
+	return x;
+}
+
 // Minimum over the 16 lanes of a DPP row, left in every lane of the row: xor 1 and xor 2 inside the
 // quads, then the half-row and row mirrors (the values are already uniform per quad / per half).
 PT_DEV uint32_t row_min_u32(uint32_t x) {
@@ -564,6 +580,14 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			const float d = length3(p - ray.o);
 			const int cur_obj = __float_as_int(wp.s2[path].w);
 			if (d < cur_d || (d == cur_d && cur_obj >= 0 && obj_index < cur_obj)) {
+				if (FLAT == 5) {
+					// mode 5 keeps only (t, triangle) per leaf; u and v are the test's own values, taken
+					// once for the triangle that won (same operations, same bits)
+					float t_, u_, v_;
+					const float4 a = pa[ts.tri], e1 = pe1[ts.tri], e2 = pe2[ts.tri];
+					(void)tri_test_flat(ray, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t_, u_, v_);
+					ts.bu = u_; ts.bv = v_;
+				}
 				wp.s0[path].w = d;
 				wp.s1[path].w = ts.tmin;
 				wp.s2[path].w = __int_as_float(obj_index);
@@ -672,6 +696,101 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 
 		// ---- leaves: two owners per step, one per half-wave ----
 		unsigned long long m = __ballot(state == LEAF);
+		if (FLAT == 5) {
+			// Boxed groups (pt_scene.h, tri_grp / grp_box). A leaf of the reference's builder holds 17..33
+			// triangles and a ray that enters its box passes most of them by: here every LEAF lane first
+			// tests the boxes of its leaf's groups of eight, one group per iteration, and appends a work
+			// unit (its slot, the group) to the wave's list for every box it touches; then the wave tests
+			// the listed groups, SIXTEEN per step, four lanes per group and two triangles per lane in
+			// packed FP32. The hits of a unit are reduced inside the quad (DPP) to the smallest t and,
+			// among equal t, the smallest slot of the unsorted run, and merged into the owner's 64-bit
+			// key (t bits << 32 | slot) with an LDS atomic minimum: exactly what the reference's loop over
+			// the run with strict '<' keeps. Skipping a group changes nothing: its box contains its
+			// triangles with padding far above the rounding of either test, so a skipped group has no hit.
+			// Leaves of any size: a leaf of n triangles has ceil(n / 8) groups; when the list is full the
+			// wave works it off and carries on with the remaining groups.
+			unsigned char* area = reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * WF_GRP_WAVE_BYTES;
+			float4* rays = reinterpret_cast<float4*>(area);
+			unsigned long long* keys = reinterpret_cast<unsigned long long*>(area + 64 * 2 * 16);
+			unsigned short* units = reinterpret_cast<unsigned short*>(area + 64 * 2 * 16 + 64 * 8);
+			const float4* __restrict__ gb = sc.grp_box;
+			const float4* __restrict__ tg = sc.tri_grp;
+			const unsigned long long lt = (1ull << lane) - 1ull;
+			const bool isleaf = state == LEAF;
+			const int rank = (int)__popcll(m & lt);
+			const int ngroups = isleaf ? (leaf_count + 7) >> 3 : 0;
+			if (isleaf) {
+				rays[2 * rank] = make_float4(ray.o.x, ray.o.y, ray.o.z, __int_as_float(leaf_block));
+				rays[2 * rank + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
+				keys[rank] = ~0ull;
+			}
+			int g = 0;
+			for (;;) {
+				// ---- fill: one group box per LEAF lane and iteration ----
+				int nunits = 0;
+				while (nunits <= WF_UNIT_CAP - 64) {
+					const bool more = g < ngroups;
+					if (__ballot(more) == 0ull) break;
+					bool touch = false;
+					if (more) {
+						const float4* bx = gb + 2 * (size_t)(4 * leaf_block + g);
+						const float4 lo = bx[0], hi = bx[1];
+						// slab test on min/max (a NaN from 0 * inf drops out: that axis does not constrain)
+						const float ax = (lo.x - ray.o.x) * ray.inv.x, bx_ = (hi.x - ray.o.x) * ray.inv.x;
+						const float ay = (lo.y - ray.o.y) * ray.inv.y, by = (hi.y - ray.o.y) * ray.inv.y;
+						const float az = (lo.z - ray.o.z) * ray.inv.z, bz = (hi.z - ray.o.z) * ray.inv.z;
+						const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx_), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+						const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx_), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+						touch = !(tn > tf) && !(tf < 0.0f);
+					}
+					const unsigned long long tm = __ballot(touch);
+					if (touch) units[nunits + (int)__popcll(tm & lt)] = (unsigned short)(rank | (g << 6));
+					nunits += (int)__popcll(tm);
+					++g;
+				}
+				__builtin_amdgcn_wave_barrier();
+				// ---- work the list off: 16 units per step ----
+				for (int s16 = 0; s16 < nunits; s16 += 16) {
+					const int ui = s16 + (lane >> 2);
+					const bool on = ui < nunits;
+					const uint32_t un = units[on ? ui : s16];
+					const int owner = (int)(un & 63u), grp = (int)(un >> 6);
+					const float4 r0 = rays[2 * owner], r1 = rays[2 * owner + 1];
+					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128; dg3 += 128; } }
+					if (on) {   // uniform per quad
+						const float4* bp = tg + ((size_t)(4 * __float_as_int(r0.w) + grp) * PT_GRP_BLOCK_F4 + (lane & 3));
+						const float4 c0 = bp[0], c1 = bp[4], c2 = bp[8], c3 = bp[12], c4 = bp[16];
+						f3x2 va, e1, e2;
+						va.x = (v2f){c0.x, c0.y}; va.y = (v2f){c0.z, c0.w}; va.z = (v2f){c1.x, c1.y};
+						e1.x = (v2f){c1.z, c1.w}; e1.y = (v2f){c2.x, c2.y}; e1.z = (v2f){c2.z, c2.w};
+						e2.x = (v2f){c3.x, c3.y}; e2.y = (v2f){c3.z, c3.w}; e2.z = (v2f){c4.x, c4.y};
+						v2f t, u, v;
+						const uint32_t hb = tri_test_flat_x2(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), va, e1, e2, t, u, v);
+						if (FLAGS & PT_F_STATS) { act += 2; dg2 += 2; }
+						if (__ballot(hb != 0u) != 0ull) {
+							// a hit has t > 5e-8, so its bit pattern orders like its value; 0xffffffff = no hit
+							const uint32_t k0 = (hb & 1u) ? __float_as_uint(t.x) : 0xffffffffu;
+							const uint32_t k1 = (hb & 2u) ? __float_as_uint(t.y) : 0xffffffffu;
+							const uint32_t k = quad_min_u32(k0 < k1 ? k0 : k1);
+							const uint32_t s0 = __float_as_uint(c4.z), s1 = __float_as_uint(c4.w);   // slots in the unsorted run
+							const uint32_t cand = quad_min_u32(umin3(k0 == k ? s0 : 0xffffffffu, k1 == k ? s1 : 0xffffffffu, 0xffffffffu));
+							if ((lane & 3) == 0 && k != 0xffffffffu)
+								atomicMin(&keys[owner], ((unsigned long long)k << 32) | (unsigned long long)cand);
+						}
+					}
+				}
+				__builtin_amdgcn_wave_barrier();
+				if (__ballot(g < ngroups) == 0ull) break;
+			}
+			if (isleaf) {
+				const unsigned long long key = keys[rank];
+				if (key != ~0ull) {
+					ts.intersects = true;
+					const float tt = __uint_as_float((uint32_t)(key >> 32));
+					if (tt < ts.tmin) { ts.tmin = tt; ts.tri = leaf_first + (int)(uint32_t)key; }
+				}
+			}
+		} else
 		if (FLAT == 4) {
 			// Mode 3's step (four owners, one per 16-lane quarter, two triangles per lane in packed FP32)
 			// with the hand-over moved to LDS. Every LEAF lane writes its ray and leaf run ONCE per round

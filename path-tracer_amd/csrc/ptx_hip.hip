@@ -4,6 +4,8 @@
 // entry point returns an error.
 #include "pt_wavefront.h"
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 
 #include <cstdarg>
 #include <cstdio>
@@ -262,6 +264,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	std::vector<float4> nodes, geom, shade, mats;
 	nodes.reserve((size_t)d->num_nodes * 4);
 	std::vector<float4> pairs;   // tri_pair blocks (pt_scene.h)
+	std::vector<float4> grp_tris, grp_boxes;   // tri_grp / grp_box (pt_scene.h)
 	geom.reserve((size_t)d->num_leaf_tris * 3);
 	shade.reserve((size_t)d->num_leaf_tris * 4);
 	int scene_max_depth = 0;
@@ -304,6 +307,13 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 		dv.first_node = base;
 		dv.root_node = base;
 		for (int k = 0; k < 3; ++k) { dv.bmin[k] = on[0].bmin[k]; dv.bmax[k] = on[0].bmax[k]; }
+		float grp_pad = 0.0f;   // padding of the group boxes (pt_scene.h): absolute + relative to the mesh size
+		{
+			double dg = 0.0;
+			for (int k = 0; k < 3; ++k) dg += ((double)on[0].bmax[k] - on[0].bmin[k]) * ((double)on[0].bmax[k] - on[0].bmin[k]);
+			grp_pad = 5e-5f + 1e-5f * (float)sqrt(dg);
+			if (!(grp_pad < 1e30f)) grp_pad = 1e30f;
+		}
 
 		// Walk the tree from the root: checks that it IS a tree (every node reached once, so the
 		// device loop terminates) and measures its depth for the LDS stack.
@@ -366,6 +376,45 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 					}
 				}
 				rec[0] = make_float4(as_float(block_first), 0.0f, 0.0f, 0.0f);
+				// and as boxed groups of eight, sorted along the longest axis of the leaf's box (pt_scene.h)
+				{
+					const float inf = __builtin_huge_valf();
+					grp_tris.resize((size_t)(block_first + nblocks) * 4 * PT_GRP_BLOCK_F4, make_float4(0, 0, 0, 0));
+					grp_boxes.resize((size_t)(block_first + nblocks) * 4 * 2, make_float4(0, 0, 0, 0));
+					for (int g = 0; g < nblocks * 4; ++g) {
+						grp_boxes[(size_t)(block_first * 4 + g) * 2] = make_float4(inf, inf, inf, 0.0f);
+						grp_boxes[(size_t)(block_first * 4 + g) * 2 + 1] = make_float4(-inf, -inf, -inf, 0.0f);
+					}
+					int axis = 0;
+					for (int k = 1; k < 3; ++k) if (nd.bmax[k] - nd.bmin[k] > nd.bmax[axis] - nd.bmin[axis]) axis = k;
+					std::vector<std::pair<double, int> > order((size_t)nd.num_tris);
+					for (int k = 0; k < nd.num_tris; ++k) {
+						const PtxTriangle& t = d->triangles[o.first_triangle + d->leaf_tris[o.first_leaf_tri + nd.first_tri + k]];
+						order[(size_t)k] = std::make_pair(3.0 * (double)t.a[axis] + (double)t.e1[axis] + (double)t.e2[axis], k);
+					}
+					std::stable_sort(order.begin(), order.end());   // equal keys keep run order
+					for (int j = 0; j < nd.num_tris; ++j) {
+						const int k = order[(size_t)j].second;
+						const PtxTriangle& t = d->triangles[o.first_triangle + d->leaf_tris[o.first_leaf_tri + nd.first_tri + k]];
+						const float comp[9] = {t.a[0], t.a[1], t.a[2], t.e1[0], t.e1[1], t.e1[2], t.e2[0], t.e2[1], t.e2[2]};
+						const size_t gi = (size_t)block_first * 4 + (size_t)(j / 8);
+						const int r = j % 8, ln = r % 4, hi = r / 4;
+						for (int c = 0; c < 9; ++c) {
+							float4& q = grp_tris[gi * PT_GRP_BLOCK_F4 + (size_t)(c / 2) * 4 + ln];
+							(&q.x)[(c % 2) * 2 + hi] = comp[c];
+						}
+						(&grp_tris[gi * PT_GRP_BLOCK_F4 + 16 + ln].x)[2 + hi] = as_float(k);
+						float4& lo = grp_boxes[gi * 2];
+						float4& up = grp_boxes[gi * 2 + 1];
+						for (int c = 0; c < 3; ++c) {
+							const float v[3] = {t.a[c], t.a[c] + t.e1[c], t.a[c] + t.e2[c]};
+							for (int z = 0; z < 3; ++z) {
+								if (v[z] - grp_pad < (&lo.x)[c]) (&lo.x)[c] = v[z] - grp_pad;
+								if (v[z] + grp_pad > (&up.x)[c]) (&up.x)[c] = v[z] + grp_pad;
+							}
+						}
+					}
+				}
 			} else {
 				float l[6] = {0, 0, 0, 0, 0, 0}, r[6] = {0, 0, 0, 0, 0, 0};
 				if (nd.left != -1) {
@@ -441,6 +490,10 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	}
 	if (pairs.empty()) pairs.push_back(make_float4(0, 0, 0, 0));
 	UP(pairs, tri_pair)
+	if (grp_tris.empty()) grp_tris.push_back(make_float4(0, 0, 0, 0));
+	if (grp_boxes.empty()) grp_boxes.push_back(make_float4(0, 0, 0, 0));
+	UP(grp_tris, tri_grp)
+	UP(grp_boxes, grp_box)
 	UP(shade, tri_shade)
 	UP(mats, materials)
 #undef UP
@@ -629,24 +682,30 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				const int obj = scene->big_object[k];
 				prof_mark(ctx, 0);
 #define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
-#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
+#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : (T) == 5 ? WF_GRP_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
 				// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
-				// descent threshold, leaf mode>. Leaf modes: 4 = four leaves per step, two triangles per lane in
-				// packed FP32, rays handed over through LDS and hits reduced with DPP (needs WF_STAGE_BYTES of
-				// LDS behind the stacks; deeper trees fall back to mode 3); 3 = the same step with the rays
-				// broadcast by shuffles and the hits folded one by one; 1 = two leaves per step, branch-free
-				// scalar test; 0 = same with the early-exit test; 2 = mode 1 with two steps' loads in flight.
-				// PTX_TRAV_VARIANT / ptx_ctx_tune select the earlier designs for A/B runs (tools/sweep.sh);
-				// measured on the bench workload, 64-sample passes (Mrays/s):
-				//   0: 2008   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
-				//   3: descent waits for every lane (1350)   4: early-exit test   5: two steps in flight (slower)
+				// descent threshold, leaf mode>. Leaf modes (pt_wavefront.h):
+				//   5 = boxed groups of eight triangles inside the leaves: group boxes per lane, the touched
+				//       groups sixteen per step (needs WF_GRP_BYTES of LDS behind the stacks)
+				//   4 = whole leaves, four per step, two triangles per lane in packed FP32, rays handed over
+				//       through LDS and hits reduced with DPP (needs WF_STAGE_BYTES)
+				//   3 = the same step with the rays broadcast by shuffles and the hits folded one by one
+				//   1 = two leaves per step, branch-free scalar test; 0 = same with the early-exit test;
+				//   2 = mode 1 with two steps' loads in flight.
+				// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
+				// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
+				//   0: 2977   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+				//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
 				//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
+				//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with the register bound of 5 waves/SIMD (2975)
 				const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
+				const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
 				if (collect_stats) {
 					if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
 					else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
 					else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
-					else COOP(PT_F_STATS, 4, 64, 32, 4);
+					else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
+					else COOP(PT_F_STATS, 4, 64, 32, 5);
 				} else switch (ctx->trav_variant) {
 					case 1: TRAV(0, 1, 3, 0); break;
 					case 2: TRAV(0, 1, 3, 64); break;
@@ -656,7 +715,13 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 					case 6: COOP(0, 7, 64, 32, 1); break;
 					case 7: COOP(0, 4, 64, 32, 3); break;
 					case 8: if (stage_fits) COOP(0, 4, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
-					default: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
+					case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
+					case 10: if (grp_fits) COOP(0, 5, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
+					default:
+						if (grp_fits) COOP(0, 4, 64, 32, 5);
+						else if (stage_fits) COOP(0, 5, 64, 32, 4);
+						else COOP(0, 4, 64, 32, 3);
+						break;
 				}
 #undef TRAV
 #undef COOP

@@ -145,7 +145,7 @@ def test_full_size_lamborghini_matches_oracle(pt, orc, ctx):
     gpuops.render_init(ctx, cam)
     acc_o, st_o = orc.render(desc, cam, 3, 1, 7, nthreads=16)
     try:
-        for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
+        for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
             pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", variant))
             for stats in (True, False):
                 acc_g, st_g = gpuops.render(ctx, scene, cam, 3, 1, 7, stats=stats)
