@@ -235,6 +235,14 @@ int ptx_timer_end(PtxCtx* ctx, float* elapsed_ms);
  * object (rayIntersectsObject, src/intersect.cuh:260-319). */
 int ptx_trace_rays(PtxCtx* ctx, const PtxScene* scene, int n, const float* origins, const float* dirs,
                    int object, PtxHit* hits_host);
+/* reference: src/intersect.cuh:260-319 rayIntersectsObject for ONE multi-node mesh, like ptx_trace_rays
+ * with that `object`, but the rays run through the PRODUCTION traversal kernel of the wavefront
+ * pipeline (root box test, queue, the kernel variant ptx_ctx_tune("trav_variant") selects), so that
+ * kernel can be checked ray by ray. Fills hit, object, prim, t_bits and bary; the counters, leaf_hash,
+ * point and normal stay zero. Fails with PTX_E_INVALID for spheres and single-leaf meshes (they have no
+ * traversal queue). */
+int ptx_trace_rays_queued(PtxCtx* ctx, const PtxScene* scene, int n, const float* origins, const float* dirs,
+                          int object, PtxHit* hits_host);
 /* reference: src/pathtracing.cu:73-94 generatePrimaryRays (+ :107-129 jitterPrimaryRays when
  * sample >= 0). Writes width*height*3 floats each, pixel index = x + y*width. */
 int ptx_generate_rays(PtxCtx* ctx, const PtxCamera* cam, int sample, uint64_t seed,

@@ -1092,6 +1092,43 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	if (FLAGS & PT_F_STATS) diag_flush(wp.stats, dg0, dg1, dg2, dg3);
 }
 
+// Parity harness (ptx_trace_rays_queued): caller rays become the paths of a one-queue pass, so that the
+// PRODUCTION traversal kernel can be checked ray by ray against the oracle. Fill = what the segment
+// kernel does for a new ray and one multi-node mesh: empty closest-hit record, root box test, enqueue.
+__global__ __launch_bounds__(PT_BLOCK) void wfq_fill_kernel(DevScene sc, WfParams wp, int n, const float* __restrict__ origins,
+                                                            const float* __restrict__ dirs, int obj_index, int slot_index) {
+	const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	const DevObject& ob = sc.objects[obj_index];
+	bool enter = false;
+	if (i < n) {
+		Ray ray;
+		init_ray(ray, mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), mk3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]));
+		float rd;
+		enter = box_test(ob.bmin[0], ob.bmin[1], ob.bmin[2], ob.bmax[0], ob.bmax[1], ob.bmax[2], ray, rd);
+		wp.s0[i] = make_float4(ray.o.x, ray.o.y, ray.o.z, __builtin_huge_valf());
+		wp.s1[i] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
+		wp.s2[i] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(-1));
+		wp.s3[i] = make_float4(__int_as_float(-1), 0.0f, 0.0f, 0.0f);
+	}
+	const int slot = wave_append(&WF_CNT(wp, 0, 1 + slot_index), enter);
+	if (enter) wp.queue[slot_index][slot] = i;
+}
+
+__global__ __launch_bounds__(PT_BLOCK) void wfq_result_kernel(DevScene sc, WfParams wp, int n, int obj_index, PtxHit* __restrict__ hits) {
+	const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const float4 a0 = wp.s0[i], a2 = wp.s2[i], a3 = wp.s3[i];
+	const int obj = __float_as_int(a2.w), tri = __float_as_int(a3.x);
+	PtxHit h;
+	memset(&h, 0, sizeof(h));
+	h.hit = obj >= 0 ? 1 : 0;
+	h.object = obj;
+	h.prim = (obj >= 0 && tri >= 0) ? __float_as_int(sc.tri_geom[3 * tri + 2].y) : -1;
+	h.t_bits = __float_as_uint(a0.w);
+	if (obj >= 0) { h.bary[0] = 1.0f - a3.y - a3.z; h.bary[1] = a3.y; h.bary[2] = a3.z; }   // src/intersect.cuh:296
+	hits[i] = h;
+}
+
 // reference: src/pathtracing.cu:151 acc_image[index] += make_float4(radiance), once per iteration, in order
 __global__ __launch_bounds__(PT_BLOCK) void wf_accumulate_kernel(float4* __restrict__ accum, const float4* __restrict__ rad,
                                                                  int npix, int batch) {

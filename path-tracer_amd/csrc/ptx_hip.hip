@@ -605,6 +605,57 @@ static int check_scene(const PtxCtx* ctx, const PtxScene* scene, const char* who
 	return PTX_OK;
 }
 
+// One traversal launch of the wavefront pipeline: the rays queued for multi-node mesh `obj` (queue k).
+static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams& wp, int obj, int k, int collect_stats) {
+	const int cus = 256;
+	const size_t tb = (size_t)cus * (size_t)ctx->trav_blocks_per_cu; // persistent waves, each owns queue/waves entries
+	const size_t lds = stack_lds_bytes(scene);
+#define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
+#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : (T) == 5 ? WF_GRP_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
+	// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
+	// descent threshold, leaf mode>. Leaf modes (pt_wavefront.h):
+	//   5 = boxed groups of eight triangles inside the leaves: group boxes per lane, the touched
+	//       groups sixteen per step (needs WF_GRP_BYTES of LDS behind the stacks)
+	//   4 = whole leaves, four per step, two triangles per lane in packed FP32, rays handed over
+	//       through LDS and hits reduced with DPP (needs WF_STAGE_BYTES)
+	//   3 = the same step with the rays broadcast by shuffles and the hits folded one by one
+	//   1 = two leaves per step, branch-free scalar test; 0 = same with the early-exit test;
+	//   2 = mode 1 with two steps' loads in flight.
+	// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
+	// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
+	//   0: 2977   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+	//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
+	//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
+	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with the register bound of 5 waves/SIMD (2975)
+	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
+	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
+	if (collect_stats) {
+		if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
+		else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
+		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
+		else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
+		else COOP(PT_F_STATS, 4, 64, 32, 5);
+	} else switch (ctx->trav_variant) {
+		case 1: TRAV(0, 1, 3, 0); break;
+		case 2: TRAV(0, 1, 3, 64); break;
+		case 3: COOP(0, 4, 64, 0, 3); break;
+		case 4: COOP(0, 3, 32, 32, 0); break;
+		case 5: COOP(0, 3, 32, 32, 2); break;
+		case 6: COOP(0, 7, 64, 32, 1); break;
+		case 7: COOP(0, 4, 64, 32, 3); break;
+		case 8: if (stage_fits) COOP(0, 4, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
+		case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
+		case 10: if (grp_fits) COOP(0, 5, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
+		default:
+			if (grp_fits) COOP(0, 4, 64, 32, 5);
+			else if (stage_fits) COOP(0, 5, 64, 32, 4);
+			else COOP(0, 4, 64, 32, 3);
+			break;
+	}
+#undef TRAV
+#undef COOP
+}
+
 extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
                                   uint64_t seed, int collect_stats) {
 	int rc = check_scene(ctx, scene, "ptx_render_samples");
@@ -677,54 +728,8 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 			HIP_TRY(hipGetLastError());
 			if (wp.is_last) break;
 			for (int k = 0; k < scene->num_big; ++k) {
-				const size_t tb = (size_t)cus * (size_t)ctx->trav_blocks_per_cu; // persistent waves, each owns queue/waves entries
-				const size_t lds = stack_lds_bytes(scene);
-				const int obj = scene->big_object[k];
 				prof_mark(ctx, 0);
-#define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
-#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : (T) == 5 ? WF_GRP_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
-				// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
-				// descent threshold, leaf mode>. Leaf modes (pt_wavefront.h):
-				//   5 = boxed groups of eight triangles inside the leaves: group boxes per lane, the touched
-				//       groups sixteen per step (needs WF_GRP_BYTES of LDS behind the stacks)
-				//   4 = whole leaves, four per step, two triangles per lane in packed FP32, rays handed over
-				//       through LDS and hits reduced with DPP (needs WF_STAGE_BYTES)
-				//   3 = the same step with the rays broadcast by shuffles and the hits folded one by one
-				//   1 = two leaves per step, branch-free scalar test; 0 = same with the early-exit test;
-				//   2 = mode 1 with two steps' loads in flight.
-				// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
-				// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
-				//   0: 2977   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
-				//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
-				//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
-				//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with the register bound of 5 waves/SIMD (2975)
-				const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
-				const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
-				if (collect_stats) {
-					if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
-					else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
-					else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
-					else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
-					else COOP(PT_F_STATS, 4, 64, 32, 5);
-				} else switch (ctx->trav_variant) {
-					case 1: TRAV(0, 1, 3, 0); break;
-					case 2: TRAV(0, 1, 3, 64); break;
-					case 3: COOP(0, 4, 64, 0, 3); break;
-					case 4: COOP(0, 3, 32, 32, 0); break;
-					case 5: COOP(0, 3, 32, 32, 2); break;
-					case 6: COOP(0, 7, 64, 32, 1); break;
-					case 7: COOP(0, 4, 64, 32, 3); break;
-					case 8: if (stage_fits) COOP(0, 4, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
-					case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
-					case 10: if (grp_fits) COOP(0, 5, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
-					default:
-						if (grp_fits) COOP(0, 4, 64, 32, 5);
-						else if (stage_fits) COOP(0, 5, 64, 32, 4);
-						else COOP(0, 4, 64, 32, 3);
-						break;
-				}
-#undef TRAV
-#undef COOP
+				launch_traversal(ctx, scene, wp, scene->big_object[k], k, collect_stats);
 				prof_mark(ctx, 0);
 				HIP_TRY(hipGetLastError());
 			}
@@ -905,6 +910,48 @@ extern "C" int ptx_trace_rays(PtxCtx* ctx, const PtxScene* scene, int n, const f
 	HIP_TRY(hipMemcpyAsync(d_d.p, dirs, rb, hipMemcpyHostToDevice, ctx->stream));
 	hipLaunchKernelGGL(trace_kernel, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), stack_lds_bytes(scene), ctx->stream,
 	                   scene->dev, n, (const float*)d_o.p, (const float*)d_d.p, object, (PtxHit*)d_h.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(hits_host, d_h.p, (size_t)n * sizeof(PtxHit), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
+extern "C" int ptx_trace_rays_queued(PtxCtx* ctx, const PtxScene* scene, int n, const float* origins, const float* dirs,
+                                     int object, PtxHit* hits_host) {
+	int rc = check_scene(ctx, scene, "ptx_trace_rays_queued");
+	if (rc != PTX_OK) return rc;
+	if (n < 0 || (n > 0 && (!origins || !dirs || !hits_host))) return fail(PTX_E_INVALID, "ptx_trace_rays_queued: bad ray arrays");
+	int slot = -1;
+	for (int k = 0; k < scene->num_big && k < PT_MAX_BIG; ++k) if (scene->big_object[k] == object) slot = k;
+	if (slot < 0) return fail(PTX_E_INVALID, "ptx_trace_rays_queued: object %d is not a multi-node mesh with a traversal queue", object);
+	if (n == 0) return PTX_OK;
+	HIP_TRY(hipSetDevice(ctx->device));
+	DevBuf d_o, d_d, d_h, d_s, d_q, d_c;
+	const size_t rb = (size_t)n * 3 * sizeof(float);
+	const size_t ncnt = 2 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG);
+	HIP_TRY(hipMalloc(&d_o.p, rb));
+	HIP_TRY(hipMalloc(&d_d.p, rb));
+	HIP_TRY(hipMalloc(&d_h.p, (size_t)n * sizeof(PtxHit)));
+	HIP_TRY(hipMalloc(&d_s.p, (size_t)n * 4 * sizeof(float4)));
+	HIP_TRY(hipMalloc(&d_q.p, (size_t)n * sizeof(int)));
+	HIP_TRY(hipMalloc(&d_c.p, ncnt * sizeof(int)));
+	HIP_TRY(hipMemcpyAsync(d_o.p, origins, rb, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(d_d.p, dirs, rb, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemsetAsync(d_c.p, 0, ncnt * sizeof(int), ctx->stream));
+	WfParams wp;
+	memset(&wp, 0, sizeof(wp));
+	wp.s0 = (float4*)d_s.p; wp.s1 = wp.s0 + n; wp.s2 = wp.s1 + n; wp.s3 = wp.s2 + n;
+	wp.queue[slot] = (int*)d_q.p;
+	wp.counters = (int*)d_c.p;
+	wp.stats = ctx->d_stats;
+	wp.n_total = n;
+	wp.num_big = scene->num_big;
+	const dim3 grid((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), block(PT_BLOCK);
+	hipLaunchKernelGGL(wfq_fill_kernel, grid, block, 0, ctx->stream, scene->dev, wp, n, (const float*)d_o.p, (const float*)d_d.p, object, slot);
+	HIP_TRY(hipGetLastError());
+	launch_traversal(ctx, scene, wp, object, slot, 0);
+	HIP_TRY(hipGetLastError());
+	hipLaunchKernelGGL(wfq_result_kernel, grid, block, 0, ctx->stream, scene->dev, wp, n, object, (PtxHit*)d_h.p);
 	HIP_TRY(hipGetLastError());
 	HIP_TRY(hipMemcpyAsync(hits_host, d_h.p, (size_t)n * sizeof(PtxHit), hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(hipStreamSynchronize(ctx->stream));

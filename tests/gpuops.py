@@ -8,6 +8,16 @@ pt = importlib.import_module("path-tracer_amd")
 from orc import fptr, hits_to_arrays  # noqa: E402  (array helpers only; no oracle compute)
 
 
+def trace_queued(ctx, scene, origins, dirs, obj):
+    """The same rays through the production traversal kernel (one multi-node mesh)."""
+    n = origins.shape[0]
+    hits = (pt.PtxHit * n)()
+    o = np.ascontiguousarray(origins, np.float32)
+    d = np.ascontiguousarray(dirs, np.float32)
+    pt.check(pt.lib().ptx_trace_rays_queued(ctx, scene, n, fptr(o), fptr(d), obj, hits), "ptx_trace_rays_queued")
+    return hits_to_arrays(hits, n)
+
+
 def trace(ctx, scene, origins, dirs, obj=-1):
     n = origins.shape[0]
     hits = (pt.PtxHit * n)()

@@ -193,3 +193,80 @@ def test_degenerate_rays_bit_exact(pt, orc, ctx, name):
         bad = np.nonzero((ho[k] != hg[k]).reshape(n, -1).any(axis=1))[0]
         assert len(bad) == 0, f"{name}: {k} differs for {len(bad)} rays, first {bad[:8]}"
     assert ((ho["hit"] == 1) & (ho["object"] == 0xFFFFFFFF)).any()   # the hit-without-object case is covered
+
+
+def _mesh_rays(desc, cam, orc, obj, rng, n_rand=6000):
+    """Adversarial rays for one mesh: primary rays, random rays through its box, rays aimed exactly AT triangle
+    vertices and edge midpoints (several triangles share them: equal-t ties, group-box faces), axis-parallel
+    rays through vertices (inverse direction +-inf), rays starting on the surface, degenerate directions."""
+    import ctypes
+    d = desc.contents
+    ob = d.objects[obj]
+    tris = np.ctypeslib.as_array(ctypes.cast(d.triangles, ctypes.POINTER(pt_mod.PtxTriangle * d.num_triangles)).contents)
+    tris = tris[ob.first_triangle: ob.first_triangle + ob.num_triangles]
+    a = tris["a"].astype(np.float32); b = (a + tris["e1"]).astype(np.float32); c = (a + tris["e2"]).astype(np.float32)
+    lo = np.minimum(np.minimum(a, b), c).min(axis=0); hi = np.maximum(np.maximum(a, b), c).max(axis=0)
+    ext = hi - lo
+    O, D = [], []
+    o, dd = orc.generate_rays(cam, -1, 0)
+    O.append(o); D.append(dd)
+    # random rays through the box
+    p0 = (lo - ext + rng.random((n_rand, 3)) * 3 * ext).astype(np.float32)
+    p1 = (lo + rng.random((n_rand, 3)) * ext).astype(np.float32)
+    dr = p1 - p0; dr /= np.linalg.norm(dr, axis=1, keepdims=True)
+    O.append(p0); D.append(dr.astype(np.float32))
+    # rays aimed at vertices and edge midpoints from random origins
+    t = rng.integers(0, len(a), 3000)
+    tgt = np.concatenate([a[t[:1000]], (0.5 * (a[t[1000:2000]] + b[t[1000:2000]])).astype(np.float32), c[t[2000:]]])
+    p0 = (lo - 0.5 * ext + rng.random((3000, 3)) * 2 * ext).astype(np.float32)
+    dr = tgt - p0; dr /= np.maximum(np.linalg.norm(dr, axis=1, keepdims=True), 1e-30)
+    O.append(p0); D.append(dr.astype(np.float32))
+    # axis-parallel rays through vertices
+    for ax in range(3):
+        for sgn in (1.0, -1.0):
+            v = a[rng.integers(0, len(a), 400)].copy()
+            dirv = np.zeros((400, 3), np.float32); dirv[:, ax] = sgn
+            v[:, ax] = lo[ax] - ext[ax] if sgn > 0 else hi[ax] + ext[ax]
+            O.append(v); D.append(dirv)
+    # rays leaving the surface (secondary-ray-like), incl. grazing directions in the triangle's plane
+    t = rng.integers(0, len(a), 3000)
+    w = rng.random((3000, 2)).astype(np.float32); w[w.sum(axis=1) > 1] = 1 - w[w.sum(axis=1) > 1]
+    p = (a[t] + w[:, :1] * tris["e1"][t] + w[:, 1:] * tris["e2"][t]).astype(np.float32)
+    dr = rng.normal(size=(3000, 3)).astype(np.float32)
+    dr[:500] = tris["e1"][t[:500]]
+    dr /= np.maximum(np.linalg.norm(dr, axis=1, keepdims=True), 1e-30)
+    O.append(p); D.append(dr.astype(np.float32))
+    # degenerate
+    p0 = rng.normal(0, 3, (256, 3)).astype(np.float32); dr = rng.normal(0, 1, (256, 3)).astype(np.float32)
+    dr[0:32] = 0; dr[32:64] *= 1e-20; dr[64:96] *= 1e18; p0[96:112] = np.nan; dr[112:128] = np.inf; p0[128:160] = 1e30
+    O.append(p0); D.append(dr)
+    return np.concatenate(O).astype(np.float32), np.concatenate(D).astype(np.float32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["teapot", "lamborghini", "blender_comp"])
+def test_production_traversal_kernel_ray_by_ray(pt, orc, ctx, name):
+    """ptx_trace_rays_queued: the wavefront pipeline's own traversal kernel (every leaf mode) against the oracle's
+    rayIntersectsObject, ray by ray, on rays chosen to sit on triangle vertices / edges / box faces."""
+    global pt_mod
+    pt_mod = pt
+    desc, cam = pt.load_scene(name, width=64, height=48)
+    scene = pt.host().pth_scene_device()
+    d = desc.contents
+    meshes = [i for i in range(d.num_objects) if d.objects[i].num_nodes > 1]
+    assert meshes
+    rng = np.random.default_rng(11)
+    try:
+        for obj in meshes[:3]:
+            o, dd = _mesh_rays(desc, cam, orc, obj, rng)
+            ho = orc.trace(desc, o, dd, obj)
+            assert (ho["object"] == obj).sum() > 1000
+            for variant in (0, 1, 6, 7, 9):
+                pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", variant))
+                hg = gpuops.trace_queued(ctx, scene, o, dd, obj)
+                for k in ("object", "prim", "t_bits", "bary"):
+                    bad = np.nonzero((ho[k] != hg[k]).reshape(len(o), -1).any(axis=1))[0]
+                    assert len(bad) == 0, (f"{name} object {obj} variant {variant}: {k} differs for {len(bad)} of {len(o)} rays, "
+                                           f"first {bad[:6]}: oracle {ho[k][bad[:3]]} gpu {hg[k][bad[:3]]}")
+    finally:
+        pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", -1))
