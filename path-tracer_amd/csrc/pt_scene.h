@@ -5,12 +5,13 @@
 // src/world.h:46-78, src/KDTree.cpp:152-163). Here, per scene, five flat arrays:
 //
 //   nodes      4 x float4 per node (64 B, one record = half a 128-B L2 line):
-//                q0 = (L.min.x, L.min.y, L.min.z, L.max.x)
-//                q1 = (L.max.y, L.max.z, R.min.x, R.min.y)
-//                q2 = (R.min.z, R.max.x, R.max.y, R.max.z)
+//                q0 = (L.min.x, R.min.x, L.min.y, R.min.y)
+//                q1 = (L.min.z, R.min.z, L.max.x, R.max.x)
+//                q2 = (L.max.y, R.max.y, L.max.z, R.max.z)
 //                q3 = int4(left, right, tri_first, tri_count)
 //              L/R = the CHILDREN's boxes, stored in the parent so one record serves both
-//              box tests of an inner step; left/right are scene-global node indices (-1 = none);
+//              box tests of an inner step, and interleaved so that each (left, right) pair of a
+//              component arrives in one 64-bit register pair: both tests run as packed FP32; left/right are scene-global node indices (-1 = none);
 //              tri_first/tri_count address tri_geom/tri_shade (leaves only). In INNER nodes q3.z/q3.w hold
 //              the two child links again in packed form for the cooperative traversal kernel: >= 0 node
 //              index, -1 none, and for a leaf child with 1..63 triangles 0x80000000 | block << 6 | count

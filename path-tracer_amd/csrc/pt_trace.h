@@ -110,6 +110,43 @@ PT_DEV bool tri_test_flat(const Ray& r, f3 va, f3 e1, f3 e2, float& res_t, float
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct f3x2 { v2f x, y, z; };
 PT_DEV v2f splat2(float s) { v2f r = {s, s}; return r; }
+// Both child boxes of an inner node against one ray: the (left, right) pairs of every component sit in
+// 64-bit register pairs (node layout, pt_scene.h), so the subtractions and multiplications issue as
+// packed FP32. Per box this is box_test operation for operation WITHOUT the early returns: the same
+// comparisons on the same values in the same order, so NaNs decide as in the reference; bit k of the
+// result = box k is hit, tmin[k] its entry distance (meaningful only then).
+PT_DEV uint32_t box_test_x2(const float4 q0, const float4 q1, const float4 q2, float rox, float roy, float roz,
+                            float rix, float riy, float riz, bool sx, bool sy, bool sz, float& tmin_l, float& tmin_r) {
+	const v2f minx = {q0.x, q0.y}, miny = {q0.z, q0.w}, minz = {q1.x, q1.y};
+	const v2f maxx = {q1.z, q1.w}, maxy = {q2.x, q2.y}, maxz = {q2.z, q2.w};
+	const v2f ox = splat2(rox), oy = splat2(roy), oz = splat2(roz);
+	const v2f ix = splat2(rix), iy = splat2(riy), iz = splat2(riz);
+	const v2f t1 = ((sx ? maxx : minx) - ox) * ix, t2 = ((sx ? minx : maxx) - ox) * ix;
+	const v2f t3 = ((sy ? maxy : miny) - oy) * iy, t4 = ((sy ? miny : maxy) - oy) * iy;
+	const v2f t5 = ((sz ? maxz : minz) - oz) * iz, t6 = ((sz ? minz : maxz) - oz) * iz;
+	uint32_t bits = 0;
+	{
+		float a1 = t1.x, a2 = t2.x;
+		bool fail = (a1 > t4.x) | (t3.x > a2);
+		if (t3.x > a1) a1 = t3.x;
+		if (t4.x < a2) a2 = t4.x;
+		fail = fail | (a1 > t6.x) | (t5.x > a2);
+		if (t5.x > a1) a1 = t5.x;
+		tmin_l = a1 < 0.0f ? 0.0f : a1;
+		if (!fail) bits |= 1u;
+	}
+	{
+		float a1 = t1.y, a2 = t2.y;
+		bool fail = (a1 > t4.y) | (t3.y > a2);
+		if (t3.y > a1) a1 = t3.y;
+		if (t4.y < a2) a2 = t4.y;
+		fail = fail | (a1 > t6.y) | (t5.y > a2);
+		if (t5.y > a1) a1 = t5.y;
+		tmin_r = a1 < 0.0f ? 0.0f : a1;
+		if (!fail) bits |= 2u;
+	}
+	return bits;
+}
 PT_DEV f3x2 cross3x2(const f3x2& a, const f3x2& b) {
 	f3x2 r;
 	r.x = a.y * b.z - a.z * b.y;
@@ -237,11 +274,11 @@ PT_DEV bool traverse_step(const DevScene& sc, const DevObject& ob, int obj_index
 		bool left_res = false, right_res = false;
 		if (left != -1) {
 			if (FLAGS & PT_F_STATS) cnt.n_box++;
-			left_res = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ray, left_dist) && (left_dist < ts.tmin);
+			left_res = box_test(q0.x, q0.z, q1.x, q1.z, q2.x, q2.z, ray, left_dist) && (left_dist < ts.tmin);
 		}
 		if (right != -1) {
 			if (FLAGS & PT_F_STATS) cnt.n_box++;
-			right_res = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ray, right_dist) && (right_dist < ts.tmin);
+			right_res = box_test(q0.y, q0.w, q1.y, q1.w, q2.y, q2.w, ray, right_dist) && (right_dist < ts.tmin);
 		}
 		if (left_res && right_res) {
 			// nearer child first; tie -> left first (reference :183-187)

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	}
 	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
 
-	enum { IDLE = 0, DESCEND = 1, LEAF = 2 };
+	enum { IDLE = 0, DESCEND = 1, LEAF = 2, DONE = 3 };
 	int state = IDLE;
 	int path = 0, leaf_first = 0, leaf_count = 0, leaf_block = 0;
 	float cur_d = 0.0f;
@@ -598,6 +598,10 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	};
 
 	for (;;) {
+		// ---- finished traversals are committed here, once per round: inside the descent loop the
+		// wave would run this block (a dependent load, up to four stores) in nearly every iteration,
+		// because some lane or other finishes in most of them ----
+		if (state == DONE) commit();
 		// ---- refill idle lanes from the wave's chunk ----
 		for (int attempt = 0; attempt < 2; ++attempt) {
 			const unsigned long long idle = __ballot(state == IDLE);
@@ -636,6 +640,12 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				const float4 q0 = nodes[4 * curr + 0];
 				const float4 q1 = nodes[4 * curr + 1];
 				const float4 q2 = nodes[4 * curr + 2];
+				// Both child boxes at once, packed (pt_trace.h), BEFORE the leaf / inner decision: the test is
+				// branch-free, a leaf reached through a plain link is rare, and the whole record is then
+				// fetched in one round trip instead of the links first and the boxes after the branch.
+				float left_dist, right_dist;
+				const uint32_t bb = box_test_x2(q0, q1, q2, ray.o.x, ray.o.y, ray.o.z, ray.inv.x, ray.inv.y, ray.inv.z, ray.sx, ray.sy, ray.sz,
+				                                left_dist, right_dist);
 				if (__float_as_int(q3.x) == -1 && __float_as_int(q3.y) == -1) {
 					// a leaf reached through a plain link (more than 63 triangles, or none)
 					leaf_first = __float_as_int(q3.z);
@@ -651,16 +661,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				} else {
 					const int left = __float_as_int(q3.z), right = __float_as_int(q3.w);   // packed links: pt_scene.h
 					if (FLAGS & PT_F_STATS) cnt.n_inner++;
-					float left_dist = __builtin_huge_valf(), right_dist = __builtin_huge_valf();
-					bool left_res = false, right_res = false;
-					if (left != -1) {
-						if (FLAGS & PT_F_STATS) cnt.n_box++;
-						left_res = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, ray, left_dist) && (left_dist < ts.tmin);
-					}
-					if (right != -1) {
-						if (FLAGS & PT_F_STATS) cnt.n_box++;
-						right_res = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, ray, right_dist) && (right_dist < ts.tmin);
-					}
+					const bool left_res = (left != -1) & ((bb & 1u) != 0u) & (left_dist < ts.tmin);
+					const bool right_res = (right != -1) & ((bb & 2u) != 0u) & (right_dist < ts.tmin);
+					if (FLAGS & PT_F_STATS) cnt.n_box += (left != -1 ? 1u : 0u) + (right != -1 ? 1u : 0u);
 					if (left_res && right_res) {
 						int further = right, nxt = right;
 						if (left_dist > right_dist) further = left; else nxt = left;
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 					} else if (right_res) {
 						ts.curr = right;
 					} else if (ts.sp == 0) {
-						commit();
+						state = DONE;
 					} else {
 						--ts.sp;
 						ts.curr = stack[ts.sp * PT_BLOCK];
@@ -1068,7 +1071,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 
 		// ---- owners pop ----
 		if (state == LEAF) {
-			if (ts.sp == 0) commit();
+			if (ts.sp == 0) state = DONE;
 			else {
 				--ts.sp;
 				ts.curr = stack[ts.sp * PT_BLOCK];

@@ -427,9 +427,9 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 					for (int k = 0; k < 3; ++k) { r[k] = on[nd.right].bmin[k]; r[3 + k] = on[nd.right].bmax[k]; }
 					todo.push_back(std::make_pair(nd.right, dep + 1));
 				}
-				rec[0] = make_float4(l[0], l[1], l[2], l[3]);
-				rec[1] = make_float4(l[4], l[5], r[0], r[1]);
-				rec[2] = make_float4(r[2], r[3], r[4], r[5]);
+				rec[0] = make_float4(l[0], r[0], l[1], r[1]);
+				rec[1] = make_float4(l[2], r[2], l[3], r[3]);
+				rec[2] = make_float4(l[4], r[4], l[5], r[5]);
 				// .x/.y: child node indices; .z/.w: the same links in packed form, filled in below
 				rec[3] = make_float4(as_float(nd.left == -1 ? -1 : base + nd.left), as_float(nd.right == -1 ? -1 : base + nd.right),
 				                     as_float(-1), as_float(-1));
@@ -623,10 +623,10 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   2 = mode 1 with two steps' loads in flight.
 	// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
 	// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
-	//   0: 2977   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+	//   0: 3080   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
 	//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
 	//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
-	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with the register bound of 5 waves/SIMD (2975)
+	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3000)
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
 	if (collect_stats) {
@@ -634,7 +634,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
 		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
 		else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
-		else COOP(PT_F_STATS, 4, 64, 32, 5);
+		else COOP(PT_F_STATS, 4, 128, 24, 5);
 	} else switch (ctx->trav_variant) {
 		case 1: TRAV(0, 1, 3, 0); break;
 		case 2: TRAV(0, 1, 3, 64); break;
@@ -645,9 +645,9 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		case 7: COOP(0, 4, 64, 32, 3); break;
 		case 8: if (stage_fits) COOP(0, 4, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
 		case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
-		case 10: if (grp_fits) COOP(0, 5, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
+		case 10: if (grp_fits) COOP(0, 4, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
 		default:
-			if (grp_fits) COOP(0, 4, 64, 32, 5);
+			if (grp_fits) COOP(0, 4, 128, 24, 5);
 			else if (stage_fits) COOP(0, 5, 64, 32, 4);
 			else COOP(0, 4, 64, 32, 3);
 			break;
