@@ -494,7 +494,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 
 // LDS staging area of leaf mode 5, per wave: 64 ray slots of two float4, 64 64-bit result keys and a list
 // of WF_UNIT_CAP 16-bit work units (owner slot | group << 6)
-#define WF_UNIT_CAP 512
+#define WF_UNIT_CAP 320
 #define WF_GRP_WAVE_BYTES (64 * 2 * 16 + 64 * 8 + WF_UNIT_CAP * 2)
 #define WF_GRP_BYTES ((PT_BLOCK / 64) * WF_GRP_WAVE_BYTES)
 
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			// Leaves of any size: a leaf of n triangles has ceil(n / 8) groups; when the list is full the
 			// wave works it off and carries on with the remaining groups.
 			unsigned char* area = reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * WF_GRP_WAVE_BYTES;
-			float4* rays = reinterpret_cast<float4*>(area);
+			float4* rays = reinterpret_cast<float4*>(area);                // 64 slots x 2 float4: (o, block) (d, -)
 			unsigned long long* keys = reinterpret_cast<unsigned long long*>(area + 64 * 2 * 16);
 			unsigned short* units = reinterpret_cast<unsigned short*>(area + 64 * 2 * 16 + 64 * 8);
 			const float4* __restrict__ gb = sc.grp_box;
@@ -722,34 +722,58 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			const bool isleaf = state == LEAF;
 			const int rank = (int)__popcll(m & lt);
 			const int ngroups = isleaf ? (leaf_count + 7) >> 3 : 0;
+			// slab test of a group box on min/max (a NaN from 0 * inf drops out: that axis does not constrain)
+			auto touches = [](const float4 lo, const float4 hi, f3 o, f3 inv) {
+				const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+				const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+				const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+				const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+				const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+				return !(tn > tf) && !(tf < 0.0f);
+			};
+			// ---- fill, first pass: every LEAF lane tests the boxes of the first four groups of its leaf;
+			// the four boxes are one 128-B line and are fetched together, so the pass costs one memory
+			// round trip (a leaf of up to 32 triangles has no more groups) ----
+			uint32_t tb = 0;
 			if (isleaf) {
 				rays[2 * rank] = make_float4(ray.o.x, ray.o.y, ray.o.z, __int_as_float(leaf_block));
 				rays[2 * rank + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
 				keys[rank] = ~0ull;
+				if (ngroups > 0) {   // the four slots of the run's first block exist whenever the run is not empty
+					const float4* bx = gb + 8 * (size_t)leaf_block;
+					const float4 b0 = bx[0], b1 = bx[1], b2 = bx[2], b3 = bx[3], b4 = bx[4], b5 = bx[5], b6 = bx[6], b7 = bx[7];
+					tb = (touches(b0, b1, ray.o, ray.inv) ? 1u : 0u) | (ngroups > 1 && touches(b2, b3, ray.o, ray.inv) ? 2u : 0u) |
+					     (ngroups > 2 && touches(b4, b5, ray.o, ray.inv) ? 4u : 0u) | (ngroups > 3 && touches(b6, b7, ray.o, ray.inv) ? 8u : 0u);
+				}
 			}
-			int g = 0;
+			int pending = 0;   // units of the first pass, appended at the top of the loop below
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				const bool on = (tb >> k) & 1u;
+				const unsigned long long tm = __ballot(on);
+				if (on) units[pending + (int)__popcll(tm & lt)] = (unsigned short)(rank | (k << 6));
+				pending += (int)__popcll(tm);
+			}
+			int g = 4;       // per lane: next group of the own leaf beyond the first four
 			for (;;) {
-				// ---- fill: one group box per LEAF lane and iteration ----
-				int nunits = 0;
-				while (nunits <= WF_UNIT_CAP - 64) {
-					const bool more = g < ngroups;
-					if (__ballot(more) == 0ull) break;
-					bool touch = false;
-					if (more) {
-						const float4* bx = gb + 2 * (size_t)(4 * leaf_block + g);
-						const float4 lo = bx[0], hi = bx[1];
-						// slab test on min/max (a NaN from 0 * inf drops out: that axis does not constrain)
-						const float ax = (lo.x - ray.o.x) * ray.inv.x, bx_ = (hi.x - ray.o.x) * ray.inv.x;
-						const float ay = (lo.y - ray.o.y) * ray.inv.y, by = (hi.y - ray.o.y) * ray.inv.y;
-						const float az = (lo.z - ray.o.z) * ray.inv.z, bz = (hi.z - ray.o.z) * ray.inv.z;
-						const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx_), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-						const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx_), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-						touch = !(tn > tf) && !(tf < 0.0f);
+				int nunits = pending;
+				pending = 0;
+				// ---- fill, the groups beyond the fourth (leaves of more than 32 triangles: rare), one per
+				// LEAF lane and iteration ----
+				{
+					while (nunits <= WF_UNIT_CAP - 64) {
+						const bool more = g < ngroups;
+						if (__ballot(more) == 0ull) break;
+						bool touch = false;
+						if (more) {
+							const float4* bx = gb + 2 * (size_t)(4 * leaf_block + g);
+							touch = touches(bx[0], bx[1], ray.o, ray.inv);
+						}
+						const unsigned long long tm = __ballot(touch);
+						if (touch) units[nunits + (int)__popcll(tm & lt)] = (unsigned short)(rank | (g << 6));
+						nunits += (int)__popcll(tm);
+						++g;
 					}
-					const unsigned long long tm = __ballot(touch);
-					if (touch) units[nunits + (int)__popcll(tm & lt)] = (unsigned short)(rank | (g << 6));
-					nunits += (int)__popcll(tm);
-					++g;
 				}
 				__builtin_amdgcn_wave_barrier();
 				// ---- work the list off: 16 units per step ----
