@@ -144,8 +144,9 @@ typedef struct PtxStats {
 	uint64_t trav_rays, trav_inner, trav_box, trav_tri, trav_leaf;
 	/* kernel-tuning counters of the traversal kernels (stats variant; meaning may change between versions):
 	 * per-lane kernel: diag0 = lanes holding a ray, diag1 = 64 per wave step (lane occupancy of the waves);
-	 * cooperative kernel: diag0/diag1 = descending lanes / 64 per descent iteration, diag2/diag3 = lanes
-	 * testing a triangle / 64 per leaf pass */
+	 * cooperative kernel: ticks of the constant-rate shader clock, read by lane 0 of every wave and summed
+	 * per phase: diag0 = commit + refill, diag1 = descent, diag2 = leaf phase, diag3 = the part of diag2
+	 * spent in the unit steps of leaf mode 5 (tools/phase_clock.py prints the shares) */
 	uint64_t diag0, diag1, diag2, diag3;
 } PtxStats;
 

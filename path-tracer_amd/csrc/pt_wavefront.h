@@ -492,10 +492,10 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 #define WF_STAGE_F4 4
 #define WF_STAGE_BYTES ((PT_BLOCK / 64) * 64 * WF_STAGE_F4 * 16)
 
-// LDS staging area of leaf mode 5, per wave: 64 ray slots of two float4, 64 64-bit result keys and a list
-// of WF_UNIT_CAP 16-bit work units (owner slot | group << 6)
+// LDS staging area of leaf mode 5, per wave: 64 64-bit result keys (one per lane) and a list of
+// WF_UNIT_CAP 16-bit work units (owner lane | group << 6)
 #define WF_UNIT_CAP 320
-#define WF_GRP_WAVE_BYTES (64 * 2 * 16 + 64 * 8 + WF_UNIT_CAP * 2)
+#define WF_GRP_WAVE_BYTES 4096   /* leaf phase: 64 * 8 + WF_UNIT_CAP * 2 = 1152 B; descent of mode 6: 64 node records */
 #define WF_GRP_BYTES ((PT_BLOCK / 64) * WF_GRP_WAVE_BYTES)
 
 PT_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
@@ -539,6 +539,9 @@ template <int FLAGS, int OCC, int CHUNK, int ATHRESH, int FLAT>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
 	extern __shared__ int lds_stack[];
 	const int tid = threadIdx.x, lane = tid & 63, sub = lane & 31;
+	// counting variant only: constant-rate clock read by lane 0, summed per phase into PtxStats.diag0..3
+	// (refill + commit, descent, leaf phase, of which unit steps of mode 5); tools/phase_clock.py
+#define WF_CLOCK() (((FLAGS & PT_F_STATS) && lane == 0) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
 	const bool upper = lane >= 32;
 	int* stack = lds_stack + tid;
 	const DevObject& ob = sc.objects[obj_index];
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			const float d = length3(p - ray.o);
 			const int cur_obj = __float_as_int(wp.s2[path].w);
 			if (d < cur_d || (d == cur_d && cur_obj >= 0 && obj_index < cur_obj)) {
-				if (FLAT == 5) {
+				if (FLAT >= 5) {
 					// mode 5 keeps only (t, triangle) per leaf; u and v are the test's own values, taken
 					// once for the triangle that won (same operations, same bits)
 					float t_, u_, v_;
@@ -598,6 +601,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	};
 
 	for (;;) {
+		const unsigned long long c0 = WF_CLOCK();
 		// ---- finished traversals are committed here, once per round: inside the descent loop the
 		// wave would run this block (a dependent load, up to four stores) in nearly every iteration,
 		// because some lane or other finishes in most of them ----
@@ -625,6 +629,8 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 		}
 		if (__ballot(state != IDLE) == 0ull) break;
 
+		const unsigned long long c1 = WF_CLOCK();
+		dg0 += c1 - c0;
 		// ---- descent: every lane walks inner nodes until it holds a leaf or its traversal ends ----
 		// The loop stops once no more than ATHRESH lanes are still on their way: waiting for the last
 		// few would idle the rest (measured with ATHRESH = 0: 19 % of the lanes busy per iteration);
@@ -632,14 +638,37 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 		for (int iter = 0; ; ++iter) {
 			const int n_desc = (int)__popcll(__ballot(state == DESCEND));
 			if (n_desc == 0 || (iter > 0 && n_desc <= ATHRESH)) break;
-			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; dg1 += 64; } }
+			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64;  } }
+			if (FLAT == 6) {
+				// Leaf mode 6 = mode 5 + node records fetched by the QUAD: in pass k the four lanes of a quad
+				// read the four 16-B parts of the record lane 4q + k wants (one 64-B line: one tag lookup in
+				// the L1 instead of four, the vector-memory path being this kernel's limit) straight into LDS
+				// (global_load_lds: destination = pass base + lane x 16, so the record of lane 4q + k lands
+				// contiguously at pass k, offset 64 q); every lane then reads its own record from LDS.
+				unsigned char* narea = reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * WF_GRP_WAVE_BYTES;
+				const int mine = state == DESCEND ? ts.curr : -1;
+#define WF_NODE_PASS(K) { \
+					const int want = __builtin_amdgcn_mov_dpp(mine, (K) * 0x55, 0xf, 0xf, false);   /* quad_perm [K,K,K,K] */ \
+					if (want >= 0) \
+						__builtin_amdgcn_global_load_lds(nodes + 4 * (size_t)want + (lane & 3), (__attribute__((address_space(3))) void*)(narea + (K) * 1024), 16, 0, 0); \
+				}
+				WF_NODE_PASS(0) WF_NODE_PASS(1) WF_NODE_PASS(2) WF_NODE_PASS(3)
+#undef WF_NODE_PASS
+			}
 			if (state == DESCEND) {
-				if (FLAGS & PT_F_STATS) { act++; dg0++; }
+				if (FLAGS & PT_F_STATS) { act++;  }
 				const int curr = ts.curr;
-				const float4 q3 = nodes[4 * curr + 3];
-				const float4 q0 = nodes[4 * curr + 0];
-				const float4 q1 = nodes[4 * curr + 1];
-				const float4 q2 = nodes[4 * curr + 2];
+				float4 q0, q1, q2, q3;
+				if (FLAT == 6) {
+					const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) +
+					                                                    (tid >> 6) * WF_GRP_WAVE_BYTES + (lane & 3) * 1024 + (lane >> 2) * 64);
+					q3 = rec[3]; q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
+				} else {
+					q3 = nodes[4 * curr + 3];
+					q0 = nodes[4 * curr + 0];
+					q1 = nodes[4 * curr + 1];
+					q2 = nodes[4 * curr + 2];
+				}
 				// Both child boxes at once, packed (pt_trace.h), BEFORE the leaf / inner decision: the test is
 				// branch-free, a leaf reached through a plain link is rare, and the whole record is then
 				// fetched in one round trip instead of the links first and the boxes after the branch.
@@ -699,7 +728,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 
 		// ---- leaves: two owners per step, one per half-wave ----
 		unsigned long long m = __ballot(state == LEAF);
-		if (FLAT == 5) {
+		const unsigned long long c2 = WF_CLOCK();
+		dg1 += c2 - c1;
+		if (FLAT >= 5) {
 			// Boxed groups (pt_scene.h, tri_grp / grp_box). A leaf of the reference's builder holds 17..33
 			// triangles and a ray that enters its box passes most of them by: here every LEAF lane first
 			// tests the boxes of its leaf's groups of eight, one group per iteration, and appends a work
@@ -713,14 +744,12 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			// Leaves of any size: a leaf of n triangles has ceil(n / 8) groups; when the list is full the
 			// wave works it off and carries on with the remaining groups.
 			unsigned char* area = reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * WF_GRP_WAVE_BYTES;
-			float4* rays = reinterpret_cast<float4*>(area);                // 64 slots x 2 float4: (o, block) (d, -)
-			unsigned long long* keys = reinterpret_cast<unsigned long long*>(area + 64 * 2 * 16);
-			unsigned short* units = reinterpret_cast<unsigned short*>(area + 64 * 2 * 16 + 64 * 8);
+			unsigned long long* keys = reinterpret_cast<unsigned long long*>(area);          // one result key per lane
+			unsigned short* units = reinterpret_cast<unsigned short*>(area + 64 * 8);
 			const float4* __restrict__ gb = sc.grp_box;
 			const float4* __restrict__ tg = sc.tri_grp;
 			const unsigned long long lt = (1ull << lane) - 1ull;
 			const bool isleaf = state == LEAF;
-			const int rank = (int)__popcll(m & lt);
 			const int ngroups = isleaf ? (leaf_count + 7) >> 3 : 0;
 			// slab test of a group box on min/max (a NaN from 0 * inf drops out: that axis does not constrain)
 			auto touches = [](const float4 lo, const float4 hi, f3 o, f3 inv) {
@@ -736,9 +765,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			// round trip (a leaf of up to 32 triangles has no more groups) ----
 			uint32_t tb = 0;
 			if (isleaf) {
-				rays[2 * rank] = make_float4(ray.o.x, ray.o.y, ray.o.z, __int_as_float(leaf_block));
-				rays[2 * rank + 1] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
-				keys[rank] = ~0ull;
+				keys[lane] = ~0ull;
 				if (ngroups > 0) {   // the four slots of the run's first block exist whenever the run is not empty
 					const float4* bx = gb + 8 * (size_t)leaf_block;
 					const float4 b0 = bx[0], b1 = bx[1], b2 = bx[2], b3 = bx[3], b4 = bx[4], b5 = bx[5], b6 = bx[6], b7 = bx[7];
@@ -751,7 +778,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			for (int k = 0; k < 4; ++k) {
 				const bool on = (tb >> k) & 1u;
 				const unsigned long long tm = __ballot(on);
-				if (on) units[pending + (int)__popcll(tm & lt)] = (unsigned short)(rank | (k << 6));
+				if (on) units[pending + (int)__popcll(tm & lt)] = (unsigned short)(lane | (k << 6));
 				pending += (int)__popcll(tm);
 			}
 			int g = 4;       // per lane: next group of the own leaf beyond the first four
@@ -770,30 +797,35 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 							touch = touches(bx[0], bx[1], ray.o, ray.inv);
 						}
 						const unsigned long long tm = __ballot(touch);
-						if (touch) units[nunits + (int)__popcll(tm & lt)] = (unsigned short)(rank | (g << 6));
+						if (touch) units[nunits + (int)__popcll(tm & lt)] = (unsigned short)(lane | (g << 6));
 						nunits += (int)__popcll(tm);
 						++g;
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
+				const unsigned long long c3 = WF_CLOCK();
 				// ---- work the list off: 16 units per step ----
 				for (int s16 = 0; s16 < nunits; s16 += 16) {
 					const int ui = s16 + (lane >> 2);
 					const bool on = ui < nunits;
 					const uint32_t un = units[on ? ui : s16];
 					const int owner = (int)(un & 63u), grp = (int)(un >> 6);
-					const float4 r0 = rays[2 * owner], r1 = rays[2 * owner + 1];
-					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128; dg3 += 128; } }
+					// the owner's ray and leaf come straight out of its registers (no LDS copy: the staging
+					// area stays small enough for one more wave per SIMD)
+					const f3 bo = mk3(__shfl(ray.o.x, owner, 64), __shfl(ray.o.y, owner, 64), __shfl(ray.o.z, owner, 64));
+					const f3 bd = mk3(__shfl(ray.d.x, owner, 64), __shfl(ray.d.y, owner, 64), __shfl(ray.d.z, owner, 64));
+					const int oblock = __shfl(leaf_block, owner, 64);
+					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128;  } }
 					if (on) {   // uniform per quad
-						const float4* bp = tg + ((size_t)(4 * __float_as_int(r0.w) + grp) * PT_GRP_BLOCK_F4 + (lane & 3));
+						const float4* bp = tg + ((size_t)(4 * oblock + grp) * PT_GRP_BLOCK_F4 + (lane & 3));
 						const float4 c0 = bp[0], c1 = bp[4], c2 = bp[8], c3 = bp[12], c4 = bp[16];
 						f3x2 va, e1, e2;
 						va.x = (v2f){c0.x, c0.y}; va.y = (v2f){c0.z, c0.w}; va.z = (v2f){c1.x, c1.y};
 						e1.x = (v2f){c1.z, c1.w}; e1.y = (v2f){c2.x, c2.y}; e1.z = (v2f){c2.z, c2.w};
 						e2.x = (v2f){c3.x, c3.y}; e2.y = (v2f){c3.z, c3.w}; e2.z = (v2f){c4.x, c4.y};
 						v2f t, u, v;
-						const uint32_t hb = tri_test_flat_x2(mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), va, e1, e2, t, u, v);
-						if (FLAGS & PT_F_STATS) { act += 2; dg2 += 2; }
+						const uint32_t hb = tri_test_flat_x2(bo, bd, va, e1, e2, t, u, v);
+						if (FLAGS & PT_F_STATS) { act += 2;  }
 						if (__ballot(hb != 0u) != 0ull) {
 							// a hit has t > 5e-8, so its bit pattern orders like its value; 0xffffffff = no hit
 							const uint32_t k0 = (hb & 1u) ? __float_as_uint(t.x) : 0xffffffffu;
@@ -807,10 +839,11 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
+				dg3 += WF_CLOCK() - c3;
 				if (__ballot(g < ngroups) == 0ull) break;
 			}
 			if (isleaf) {
-				const unsigned long long key = keys[rank];
+				const unsigned long long key = keys[lane];
 				if (key != ~0ull) {
 					ts.intersects = true;
 					const float tt = __uint_as_float((uint32_t)(key >> 32));
@@ -853,7 +886,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				const int count = slot < nleaf ? __float_as_int(r3.y) : 0;   // slots past nleaf hold stale data
 				uint32_t best_k = 0xffffffffu;
 				for (int base = 0; __ballot(base < count) != 0ull; base += 32) {
-					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128; dg3 += 128; } }
+					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128;  } }
 					if (base < count) {   // uniform per quarter (= per DPP row)
 						const float4* bp = pp + ((size_t)(blk + (base >> 5)) * PT_PAIR_BLOCK_F4 + sub16);
 						const float4 c0 = bp[0], c1 = bp[16], c2 = bp[32], c3 = bp[48], c4 = bp[64];
@@ -865,7 +898,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 						const uint32_t hb = tri_test_flat_x2p(bo, bd, va, e1, e2, t, u, v);
 						if (FLAGS & PT_F_STATS) {
 							const int here = (sub16 < count - base ? 1 : 0) + (sub16 + 16 < count - base ? 1 : 0);
-							act += here; dg2 += here;
+							act += here; 
 						}
 						if (__ballot(hb != 0u) != 0ull) {
 							// a hit has t > 5e-8, so its bit pattern orders like its value; 0xffffffff = no hit
@@ -938,10 +971,10 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 						hb = tri_test_flat_x2(bo, bd, va, e1, e2, t, u, v);
 						if (FLAGS & PT_F_STATS) {
 							const int here = (sub16 < count - base ? 1 : 0) + (sub16 + 16 < count - base ? 1 : 0);
-							act += here; dg2 += here;
+							act += here; 
 						}
 					}
-					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128; dg3 += 128; } }
+					if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128;  } }
 					// fold in triangle order: slot 0 holds triangles base..base+15, slot 1 base+16..base+31
 #pragma unroll
 					for (int slot = 0; slot < 2; ++slot) {
@@ -1008,7 +1041,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				float t, u, v;
 				bool hit = tri_test_flat(br, mk3(st.a.x, st.a.y, st.a.z), mk3(st.e1.x, st.e1.y, st.e1.z), mk3(st.e2.x, st.e2.y, st.e2.z), t, u, v);
 				hit = hit && st.valid;
-				if (FLAGS & PT_F_STATS) { if (st.valid) { act++; dg2++; } if (lane == 0) { tot += 64; dg3 += 64; } }
+				if (FLAGS & PT_F_STATS) { if (st.valid) { act++;  } if (lane == 0) { tot += 64;  } }
 				const unsigned long long hm = __ballot(hit);
 				uint32_t h0 = (uint32_t)hm, h1 = (uint32_t)(hm >> 32);
 				while ((h0 | h1) != 0u) {
@@ -1070,9 +1103,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 					const float4 a = pa[first + i], e1 = pe1[first + i], e2 = pe2[first + i];
 					if (FLAT) hit = tri_test_flat(br, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t, u, v);
 					else hit = tri_test(br, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t, u, v);
-					if (FLAGS & PT_F_STATS) { act++; dg2++; }
+					if (FLAGS & PT_F_STATS) { act++;  }
 				}
-				if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; dg3 += 64; } }
+				if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64;  } }
 				const unsigned long long hm = __ballot(hit);
 				uint32_t h0 = (uint32_t)hm, h1 = (uint32_t)(hm >> 32);
 				// fold the hits into the owners in triangle order (the serial loop's order)
@@ -1093,6 +1126,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			}
 		}
 
+		dg2 += WF_CLOCK() - c2;
 		// ---- owners pop ----
 		if (state == LEAF) {
 			if (ts.sp == 0) state = DONE;
@@ -1117,6 +1151,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	}
 	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
 	if (FLAGS & PT_F_STATS) diag_flush(wp.stats, dg0, dg1, dg2, dg3);
+#undef WF_CLOCK
 }
 
 // Parity harness (ptx_trace_rays_queued): caller rays become the paths of a one-queue pass, so that the

@@ -611,9 +611,10 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	const size_t tb = (size_t)cus * (size_t)ctx->trav_blocks_per_cu; // persistent waves, each owns queue/waves entries
 	const size_t lds = stack_lds_bytes(scene);
 #define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
-#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : (T) == 5 ? WF_GRP_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
+#define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : (T) >= 5 ? WF_GRP_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
 	// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
 	// descent threshold, leaf mode>. Leaf modes (pt_wavefront.h):
+	//   6 = mode 5 with the node records fetched by the quad through LDS (one L1 tag lookup per record)
 	//   5 = boxed groups of eight triangles inside the leaves: group boxes per lane, the touched
 	//       groups sixteen per step (needs WF_GRP_BYTES of LDS behind the stacks)
 	//   4 = whole leaves, four per step, two triangles per lane in packed FP32, rays handed over
@@ -623,10 +624,10 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   2 = mode 1 with two steps' loads in flight.
 	// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
 	// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
-	//   0: 3080   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+	//   0: 3200   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
 	//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
 	//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
-	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3000)
+	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3090)   11: mode 5 (3150)
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
 	if (collect_stats) {
@@ -646,8 +647,9 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		case 8: if (stage_fits) COOP(0, 4, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
 		case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
 		case 10: if (grp_fits) COOP(0, 4, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
+		case 11: if (grp_fits) COOP(0, 4, 128, 24, 5); else COOP(0, 4, 64, 32, 3); break;
 		default:
-			if (grp_fits) COOP(0, 4, 128, 24, 5);
+			if (grp_fits) COOP(0, 4, 128, 24, 6);
 			else if (stage_fits) COOP(0, 5, 64, 32, 4);
 			else COOP(0, 4, 64, 32, 3);
 			break;

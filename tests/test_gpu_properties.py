@@ -183,7 +183,7 @@ def test_fat_leaves_match_oracle(pt, orc, ctx, tmp_path):
     gpuops.render_init(ctx, cam)
     acc_o, st_o = orc.render(desc, cam, 0, 4, 6)
     try:
-        for variant in (0, 1, 6, 7, 8, 9, 10):
+        for variant in (0, 1, 6, 7, 8, 9, 10, 11):
             _tune(pt, ctx, b"trav_variant", variant)
             acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 4, 6, stats=True)
             assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32)), f"variant {variant}"
