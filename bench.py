@@ -198,11 +198,18 @@ def main():
         "valu": {"achieved": round(achieved_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(achieved_tflops / VALU_PEAK_TFLOPS, 5), "flops_per_traversal": round(f_total / tr, 1)},
         "per_traversal": {k: round(cd[k] / tr, 3) for k in ("trav_inner", "trav_box", "trav_tri", "trav_leaf")},
+        # what the kernel itself reads: the group boxes inside the leaves (leaf mode 5/6) answer most of the
+        # reference's triangle tests without touching the triangles
+        "kernel_reads": {"triangle_slots_tested_per_traversal": round(max(0, cd["lane_steps_active"] - cd["trav_inner"]) / tr, 1),
+                         "bytes_per_traversal": round((64 * cd["trav_inner"] + 128 * cd["trav_leaf"] +
+                                                       40 * max(0, cd["lane_steps_active"] - cd["trav_inner"])) / tr + 64, 1)},
         "segment_kernel": {"launch_ms": round(float(seg_ms.value) / max(1, seg_n.value), 4), "launches": seg_n.value},
         "step_kernel_ms": round(float(kernel_ms.value) / args.steps, 3),
-        "note": "achieved = logical bytes the traversal consumes / launch time; the 21 MB tree + triangle set is served by "
-                "L1/L2/Infinity Cache, so this can exceed the HBM peak - traffic is the measured L2-miss side, valu the "
-                "compute bound that actually binds (DESIGN.md, Roofline)",
+        "note": "achieved = the ALGORITHMIC bytes of the reference traversal (56 B per inner step, 40 B per triangle test of "
+                "its leaves, 64 B per ray; SURVEY 8d) / launch time. It exceeds the HBM peak for two reasons: the tree and "
+                "triangle set are served by L1/L2/Infinity Cache (traffic = the measured L2-miss side), and the kernel "
+                "answers most of the reference's triangle tests from group boxes without reading the triangles "
+                "(kernel_reads). What binds is instruction issue and the vector-memory path (DESIGN.md, Roofline)",
     }
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------
