@@ -40,8 +40,10 @@
 //              per 32-triangle block of the run, so group j of a run starting at block b is entry 4b + j
 //              of both arrays; a run of n triangles uses ceil(n / 8) of them.
 //                grp_box: 2 float4 per group (min.xyz, -) (max.xyz, -): the triangles' vertices, padded by
-//                  5e-5 + 1e-5 x the mesh diagonal so that a ray that hits a triangle cannot miss its
-//                  group's box through rounding (unused entries: an inverted box, never hit)
+//                  5e-5 + 1e-4 x the mesh diagonal (ptx_ctx_tune "grp_pad_ppm", default 100) so that a ray
+//                  the triangle test accepts does not miss its group's box through the rounding of either
+//                  test (tools/grazing_stress.py: no difference from the oracle even at 0 ppm; unused
+//                  entries are never consulted)
 //                tri_grp: PT_GRP_BLOCK_F4 float4 per group: 5 planes x 4 float4, plane c entry l =
 //                  (X[l], X[l+4], Y[l], Y[l+4]) for the tri_pair component pairs; plane 4 carries in
 //                  .z/.w the triangles' slots in the UNSORTED run (int), which is what a hit reports and

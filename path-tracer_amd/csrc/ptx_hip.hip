@@ -55,6 +55,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
+	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
 };
@@ -102,8 +103,10 @@ static int env_int(const char* name, int dflt) {
 	return e ? atoi(e) : dflt;
 }
 
+#define PT_GRP_PAD_PPM_DEFAULT 100
+
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm;
 	bool force_megakernel;
 };
 
@@ -118,6 +121,8 @@ static Tuning tuning_defaults() {
 	t.force_megakernel = env_int("PTX_MEGAKERNEL", 0) != 0;
 	t.trav_variant = env_int("PTX_TRAV_VARIANT", 0);
 	t.trav_blocks_per_cu = clampi(env_int("PTX_TRAV_BLOCKS", 16), 1, 64);
+	// padding of the group boxes (pt_scene.h) relative to the mesh diagonal, in parts per million; read at scene upload
+	t.grp_pad_ppm = clampi(env_int("PTX_GRP_PAD_PPM", PT_GRP_PAD_PPM_DEFAULT), 0, 1000000);
 	return t;
 }
 
@@ -127,6 +132,7 @@ static void tune_defaults(PtxCtx* c) {
 	c->force_megakernel = t.force_megakernel;
 	c->trav_variant = t.trav_variant;
 	c->trav_blocks_per_cu = t.trav_blocks_per_cu;
+	c->grp_pad_ppm = t.grp_pad_ppm;
 }
 
 extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
@@ -136,6 +142,7 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "trav_blocks")) ctx->trav_blocks_per_cu = value < 0 ? d.trav_blocks_per_cu : clampi(value, 1, 64);
 	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d.wf_batch : clampi(value, 1, 64);
 	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d.force_megakernel : value != 0;
+	else if (!strcmp(key, "grp_pad_ppm")) ctx->grp_pad_ppm = value < 0 ? d.grp_pad_ppm : clampi(value, 0, 1000000);
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
 	return PTX_OK;
 }
@@ -311,7 +318,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 		{
 			double dg = 0.0;
 			for (int k = 0; k < 3; ++k) dg += ((double)on[0].bmax[k] - on[0].bmin[k]) * ((double)on[0].bmax[k] - on[0].bmin[k]);
-			grp_pad = 5e-5f + 1e-5f * (float)sqrt(dg);
+			grp_pad = 5e-5f + 1e-6f * (float)ctx->grp_pad_ppm * (float)sqrt(dg);
 			if (!(grp_pad < 1e30f)) grp_pad = 1e30f;
 		}
 
