@@ -222,8 +222,10 @@ int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches,
 /* Scheduling knobs of the render path (no reference counterpart; results do not depend on them, the parity
  * tests run the variants against each other): key = "trav_variant" (traversal kernel variant, see
  * ptx_hip.hip), "trav_blocks" (persistent blocks per CU), "wf_batch" (samples per wavefront pass, 1..64),
- * "megakernel" (1 = one-lane-per-pixel kernel instead of the wavefront pipeline). Defaults come from the
- * environment (PTX_TRAV_VARIANT, PTX_TRAV_BLOCKS, PTX_WF_BATCH, PTX_MEGAKERNEL) at ptx_ctx_create.
+ * "megakernel" (1 = one-lane-per-pixel kernel instead of the wavefront pipeline), "grp_pad_ppm" (padding
+ * of the boxes around the groups of eight triangles inside the leaves, in parts per million of the mesh
+ * diagonal, on top of 5e-5; read by the NEXT ptx_scene_upload). Defaults come from the environment
+ * (PTX_TRAV_VARIANT, PTX_TRAV_BLOCKS, PTX_WF_BATCH, PTX_MEGAKERNEL, PTX_GRP_PAD_PPM) at ptx_ctx_create.
  * value < 0 restores that default. */
 int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value);
 /* HIP-event timer on the context's stream (for bench.py's roofline leg). */
