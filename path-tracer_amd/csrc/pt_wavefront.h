@@ -492,6 +492,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 #define WF_STAGE_F4 4
 #define WF_STAGE_BYTES ((PT_BLOCK / 64) * 64 * WF_STAGE_F4 * 16)
 
+#ifndef WF_REFILL_MIN
+#define WF_REFILL_MIN 8
+#endif
 // LDS staging area of leaf mode 5, per wave: 64 64-bit result keys (one per lane) and a list of
 // WF_UNIT_CAP 16-bit work units (owner lane | group << 6)
 #define WF_UNIT_CAP 320
@@ -605,9 +608,13 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 		// ---- finished traversals are committed here, once per round: inside the descent loop the
 		// wave would run this block (a dependent load, up to four stores) in nearly every iteration,
 		// because some lane or other finishes in most of them ----
-		if (state == DONE) commit();
+		// ... and only when enough lanes wait for it (WF_REFILL_MIN), or nothing else is left to do: with two or
+		// three traversals ending per round the whole wave would otherwise pay for this block every round.
+		const int n_wait = (int)__popcll(__ballot(state == DONE || state == IDLE));
+		const bool turn = n_wait >= WF_REFILL_MIN || n_wait == 64;
+		if (turn && state == DONE) commit();
 		// ---- refill idle lanes from the wave's chunk ----
-		for (int attempt = 0; attempt < 2; ++attempt) {
+		for (int attempt = 0; turn && attempt < 2; ++attempt) {
 			const unsigned long long idle = __ballot(state == IDLE);
 			if (idle == 0ull) break;
 			if (feed.next >= feed.hi) {
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			}
 			feed.next += (int)__popcll(idle);
 		}
-		if (__ballot(state != IDLE) == 0ull) break;
+		if (turn && __ballot(state != IDLE) == 0ull) break;
 
 		const unsigned long long c1 = WF_CLOCK();
 		dg0 += c1 - c0;
