@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--scene", default="lamborghini")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=128)
     ap.add_argument("--textures", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")

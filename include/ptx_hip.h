@@ -221,7 +221,7 @@ int ptx_profile_enable(PtxCtx* ctx, int enable);
 int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches, float* segment_ms, int32_t* segment_launches);
 /* Scheduling knobs of the render path (no reference counterpart; results do not depend on them, the parity
  * tests run the variants against each other): key = "trav_variant" (traversal kernel variant, see
- * ptx_hip.hip), "trav_blocks" (persistent blocks per CU), "wf_batch" (samples per wavefront pass, 1..64),
+ * ptx_hip.hip), "trav_blocks" (persistent blocks per CU), "wf_batch" (samples per wavefront pass, 1..256, default 128),
  * "megakernel" (1 = one-lane-per-pixel kernel instead of the wavefront pipeline), "grp_pad_ppm" (padding
  * of the boxes around the groups of eight triangles inside the leaves, in parts per million of the mesh
  * diagonal, on top of 5e-5; read by the NEXT ptx_scene_upload). Defaults come from the environment

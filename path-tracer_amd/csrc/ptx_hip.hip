@@ -116,8 +116,9 @@ static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v
 static Tuning tuning_defaults() {
 	Tuning t;
 	// samples per pass: large queues amortise the ramp/tail of the persistent traversal launches
-	// (8 -> 64: 1274 -> 1601 Mrays/s); costs 64 B x 64 x pixels of path state
-	t.wf_batch = clampi(env_int("PTX_WF_BATCH", 64), 1, 64);
+	// (8 -> 64: 1274 -> 1601 Mrays/s with the first cooperative kernel; 64 -> 128 -> 256: 3278 -> 3377 -> 3426 now);
+	// costs 100 B of state per path: 26.5 GB at 1080p x 128 samples, capped at 2^28 paths per pass
+	t.wf_batch = clampi(env_int("PTX_WF_BATCH", 128), 1, 256);
 	t.force_megakernel = env_int("PTX_MEGAKERNEL", 0) != 0;
 	t.trav_variant = env_int("PTX_TRAV_VARIANT", 0);
 	t.trav_blocks_per_cu = clampi(env_int("PTX_TRAV_BLOCKS", 16), 1, 64);
@@ -140,7 +141,7 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	const Tuning d = tuning_defaults();
 	if (!strcmp(key, "trav_variant")) ctx->trav_variant = value < 0 ? d.trav_variant : value;
 	else if (!strcmp(key, "trav_blocks")) ctx->trav_blocks_per_cu = value < 0 ? d.trav_blocks_per_cu : clampi(value, 1, 64);
-	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d.wf_batch : clampi(value, 1, 64);
+	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d.wf_batch : clampi(value, 1, 256);
 	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d.force_megakernel : value != 0;
 	else if (!strcmp(key, "grp_pad_ppm")) ctx->grp_pad_ppm = value < 0 ? d.grp_pad_ppm : clampi(value, 0, 1000000);
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
@@ -696,7 +697,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	const int tiles_x = (W + 7) / 8, tiles_y = (Hh + 7) / 8;
 	const size_t npt = (size_t)tiles_x * tiles_y * 64, npix = (size_t)W * Hh;
 	int batch = ctx->wf_batch;
-	while (batch > 1 && npt * (size_t)batch > ((size_t)1 << 27)) batch >>= 1;
+	while (batch > 1 && npt * (size_t)batch > ((size_t)1 << 28)) batch >>= 1;
 	if (batch > num_samples) batch = num_samples;
 	// 100 B of state per path: if the device cannot hold the preferred batch (other tenants, huge frames),
 	// halve it rather than fail; the result does not depend on the batch size

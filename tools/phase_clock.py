@@ -9,7 +9,7 @@ ctx = pt.host().pth_context()
 desc, cam = pt.load_scene(sys.argv[1] if len(sys.argv) > 1 else "lamborghini", 1920, 1080)
 scene = pt.host().pth_scene_device()
 gpuops.render_init(ctx, cam)
-acc, st = gpuops.render(ctx, scene, cam, 0, 64, 0, stats=True)   # 64-sample pass, as in bench.py
+acc, st = gpuops.render(ctx, scene, cam, 0, 128, 0, stats=True)   # one 128-sample pass, as in bench.py
 d = [st.diag0, st.diag1, st.diag2, st.diag3]
 tot = float(d[0] + d[1] + d[2]) or 1.0
 print("ticks : commit+refill %.3g  descent %.3g  leaf phase %.3g (of which unit steps %.3g)" % tuple(d))
