@@ -22,7 +22,7 @@
 
 int main(int argc, char** argv) {
 	std::string scene_path, out_png, out_pfm, assets;
-	int width = 0, height = 0, spp = 16, bounces = -1, textures = -1, batch = 64, car_tris = 0;
+	int width = 0, height = 0, spp = 16, bounces = -1, textures = -1, batch = 128, car_tris = 0;
 	unsigned long long seed = 0;
 	bool iterate = false;
 	std::string autosave_dir = ".", name = "render", ck_path, resume_path;
