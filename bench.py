@@ -190,7 +190,7 @@ def main():
     tr = max(1, cd["trav_rays"])
     workload_key = f"{args.scene}:{cam.width}x{cam.height}:spp{spp}:tex{args.textures}"
     roofline = {
-        "kernel": "wf_traverse_coop_kernel<0,4,128,24,6>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+        "kernel": "wf_traverse_coop_kernel<0,4,128,28,6>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": load_traffic(workload_key),
         "launch_ms": round(launch_ms, 4), "launches": trav_n.value, "bytes_per_launch": round(b_launch),
         "traversals_per_launch": round(cd["trav_rays"] / n_launch), "bytes_per_traversal": round(b_total / tr, 1),

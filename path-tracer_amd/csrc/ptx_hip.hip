@@ -632,7 +632,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   2 = mode 1 with two steps' loads in flight.
 	// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
 	// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
-	//   0: 3200   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+	//   0: 3420 (128-sample passes; the other figures are 64-sample passes)   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
 	//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
 	//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
 	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3090)   11: mode 5 (3150)
@@ -643,7 +643,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
 		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
 		else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
-		else COOP(PT_F_STATS, 4, 128, 24, 5);
+		else COOP(PT_F_STATS, 4, 128, 28, 5);
 	} else switch (ctx->trav_variant) {
 		case 1: TRAV(0, 1, 3, 0); break;
 		case 2: TRAV(0, 1, 3, 64); break;
@@ -655,9 +655,9 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		case 8: if (stage_fits) COOP(0, 4, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
 		case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
 		case 10: if (grp_fits) COOP(0, 4, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
-		case 11: if (grp_fits) COOP(0, 4, 128, 24, 5); else COOP(0, 4, 64, 32, 3); break;
+		case 11: if (grp_fits) COOP(0, 4, 128, 28, 5); else COOP(0, 4, 64, 32, 3); break;
 		default:
-			if (grp_fits) COOP(0, 4, 128, 24, 6);
+			if (grp_fits) COOP(0, 4, 128, 28, 6);
 			else if (stage_fits) COOP(0, 5, 64, 32, 4);
 			else COOP(0, 4, 64, 32, 3);
 			break;
