@@ -528,16 +528,25 @@ PT_DEV uint32_t row_min_u32(uint32_t x) {
 // Why: a KD leaf of the reference's builder holds 17..33 triangles (children only when the left half
 // is > 16, src/KDTree.cpp:96) and a ray visits ~12 leaves, so ~300 triangle tests per traversal
 // against ~50 inner nodes. One ray per lane walks those triangles serially: 64 lanes fetch 64
-// unrelated 48-B records per step (the vector memory path is 72 % busy, profiles/r01_wavefront_*)
-// and only a quarter of the lanes of a VALU instruction do useful work. Here every lane that holds
-// a leaf hands it to the wave: two leaves per step, one per 32-lane half; the owner's ray is
-// broadcast, lane i tests triangle i of the run (three contiguous 512-B plane reads), and the hits
-// are folded back into the owner's state IN TRIANGLE ORDER with the reference's strict '<', so the
-// result is exactly what the serial loop gives (first triangle wins ties).
+// unrelated 48-B records per step and only a quarter of the lanes of a VALU instruction do useful
+// work. Here every lane that holds a leaf hands it to the wave. How the wave tests it is the leaf
+// mode FLAT (history and measurements: DESIGN.md 3.2):
+//   0 / 1  two leaves per step, one per 32-lane half, lane i tests triangle i of the run (tri_soa);
+//          early-exit / branch-free scalar test; 2 = mode 1 with two steps' loads in flight
+//   3      four leaves per step, one per 16-lane quarter, two triangles per lane as register pairs in
+//          packed FP32 (tri_pair); rays broadcast by shuffles, hits folded one by one in run order
+//   4      the same step, rays handed over through LDS slots, hits reduced with DPP row minima
+//   5      boxed groups: a leaf's triangles sorted and cut into groups of eight with a box each
+//          (tri_grp, grp_box); the owner tests the group boxes, the wave tests only the touched
+//          groups, sixteen per step                                              <- default (as 6)
+//   6      mode 5 with the node records of the descent fetched by the quad through LDS
+// In every mode the hits are merged into the owner's state so that the result is exactly what the
+// reference's serial loop over the run with strict '<' gives (first triangle wins ties).
 //
 // Round structure (wave-uniform control flow throughout):
-//   refill idle lanes from the wave's queue chunk -> all lanes descend until each holds a leaf or is
-//   done -> leaves are processed two at a time -> owners pop their stacks.
+//   commit finished traversals and refill idle lanes from the wave's queue chunk (once enough lanes
+//   wait) -> all lanes descend until each holds a leaf or is done (stop at ATHRESH stragglers) ->
+//   the leaves are worked off -> owners pop their stacks.
 template <int FLAGS, int OCC, int CHUNK, int ATHRESH, int FLAT>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
 	extern __shared__ int lds_stack[];
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			}
 		}
 
-		// ---- leaves: two owners per step, one per half-wave ----
+		// ---- leaves (by leaf mode) ----
 		unsigned long long m = __ballot(state == LEAF);
 		const unsigned long long c2 = WF_CLOCK();
 		dg1 += c2 - c1;
