@@ -157,6 +157,12 @@ def test_full_size_lamborghini_matches_oracle(pt, orc, ctx):
                     assert getattr(st_o, k) == getattr(st_g, k), f"variant {variant}: counter {k}: oracle {getattr(st_o, k)} gpu {getattr(st_g, k)}"
     finally:
         pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", -1))
+    # and a longer run of the default schedule: 24 samples in one pass (about 105 M path segments)
+    acc_o8, st_o8 = orc.render(desc, cam, 10, 24, 7, nthreads=16)
+    acc_g8, st_g8 = gpuops.render(ctx, scene, cam, 10, 24, 7)
+    diff = np.nonzero((acc_o8.view(np.uint32) != acc_g8.view(np.uint32)).any(axis=1))[0]
+    assert len(diff) == 0, f"24 samples: {len(diff)} pixels differ, first {diff[:5]}"
+    assert st_o8.rays == st_g8.rays and st_o8.paths == st_g8.paths
 
 
 def test_fast_reciprocal_is_exact(pt, ctx):
