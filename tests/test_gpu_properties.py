@@ -294,3 +294,76 @@ def test_camera_change_restarts_like_the_reference(pt, orc, ctx):
     C.memmove(C.byref(bad), C.byref(cam1), C.sizeof(cam1))
     bad.width = 32
     assert L.ptx_render_set_camera(ctx, C.byref(bad)) != 0               # resolution must not change
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [40, 52])
+def test_hand_built_deep_tree_uses_the_fallback_modes(pt, orc, ctx, D):
+    """A caller-supplied tree D levels deep (a chain: every inner node has a one-triangle leaf on the left and the
+    rest on the right). At 52 levels the LDS stack leaves no room for the staging areas of leaf modes 4-6, so the
+    default falls back to mode 3; at 40 they just fit. Hits must equal the oracle's through both trace entry points
+    and every variant."""
+    import ctypes as C
+    n_tri = D + 5
+    tris = (pt.PtxTriangle * n_tri)()
+    for i in range(n_tri):
+        t = tris[i]
+        t.a[:] = [float(i), 0.0, 0.0]; t.e1[:] = [0.8, 0.0, 0.0]; t.e2[:] = [0.0, 1.0, 0.0]
+        t.na[:] = [0, 0, 1]; t.nb[:] = [0, 0, 1]; t.nc[:] = [0, 0, 1]
+        t.material = 0
+    n_nodes = 2 * D + 1
+    nodes = (pt.PtxKDNode * n_nodes)()
+
+    def box(lo, hi):   # triangles lo..hi-1
+        return [lo - 1e-4, -1e-4, -1e-4], [hi - 1 + 0.8 + 1e-4, 1 + 1e-4, 1e-4]
+    for k in range(D):
+        inner, leaf = nodes[2 * k], nodes[2 * k + 1]
+        inner.bmin[:], inner.bmax[:] = box(k, n_tri)
+        inner.left, inner.right = 2 * k + 1, 2 * (k + 1)
+        inner.first_tri, inner.num_tris = -1, 0
+        leaf.bmin[:], leaf.bmax[:] = box(k, k + 1)
+        leaf.left = leaf.right = -1
+        leaf.first_tri, leaf.num_tris = k, 1
+    last = nodes[2 * D]
+    last.bmin[:], last.bmax[:] = box(D, n_tri)
+    last.left = last.right = -1
+    last.first_tri, last.num_tris = D, n_tri - D
+    leaf_tris = (C.c_int32 * n_tri)(*range(n_tri))
+    mat = (pt.PtxMaterial * 1)()
+    mat[0].type = pt.MAT_DIFFUSE; mat[0].color[:] = [0.8, 0.8, 0.8]; mat[0].texture = -1
+    obj = (pt.PtxObject * 1)()
+    obj[0].type = 1; obj[0].first_material = 0; obj[0].num_materials = 1
+    obj[0].first_triangle = 0; obj[0].num_triangles = n_tri
+    obj[0].first_node = 0; obj[0].num_nodes = n_nodes
+    obj[0].first_leaf_tri = 0; obj[0].num_leaf_tris = n_tri; obj[0].max_depth = D
+    desc = pt.PtxSceneDesc()
+    desc.num_objects, desc.objects = 1, obj
+    desc.num_materials, desc.materials = 1, mat
+    desc.num_textures, desc.textures = 0, None
+    desc.num_triangles, desc.triangles = n_tri, tris
+    desc.num_nodes, desc.nodes = n_nodes, nodes
+    desc.num_leaf_tris, desc.leaf_tris = n_tri, leaf_tris
+    scene = C.c_void_p()
+    pt.check(pt.lib().ptx_scene_upload(ctx, C.byref(desc), C.byref(scene)))
+    try:
+        rng = np.random.default_rng(3)
+        n = 20000
+        o = np.stack([rng.uniform(-2, n_tri + 2, n), rng.uniform(-0.5, 1.5, n), rng.uniform(2, 6, n)], axis=1).astype(np.float32)
+        tgt = np.stack([rng.uniform(-2, n_tri + 2, n), rng.uniform(-0.5, 1.5, n), np.zeros(n)], axis=1)
+        d = (tgt - o); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d = d.astype(np.float32)
+        d[:2000] = [0, 0, -1]                                  # axis-parallel
+        o[2000:3000, 2] = 0.0; d[2000:3000] = [1, 0, 0]        # along the chain, in the triangles' plane
+        ho = orc.trace(C.pointer(desc), o, d, 0)
+        assert (ho["object"] == 0).sum() > 2000
+        hg = gpuops.trace(ctx, scene, o, d, 0)
+        for k in ho:
+            assert np.array_equal(ho[k], hg[k]), k
+        for variant in (0, 1, 6, 7, 9, 11):
+            _tune(pt, ctx, b"trav_variant", variant)
+            hq = gpuops.trace_queued(ctx, scene, o, d, 0)
+            for k in ("object", "prim", "t_bits", "bary"):
+                assert np.array_equal(ho[k], hq[k]), (variant, k)
+    finally:
+        _tune(pt, ctx, b"trav_variant", -1)
+        pt.lib().ptx_scene_free(ctx, scene)
