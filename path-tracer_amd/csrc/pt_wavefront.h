@@ -579,6 +579,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	}
 	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
 
+	// wave-uniform LDS byte address of this wave's staging area (leaf modes 5/6), as a scalar for the LDS-DMA base
+	const uint32_t nbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(
+		reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * WF_GRP_WAVE_BYTES));
 	enum { IDLE = 0, DESCEND = 1, LEAF = 2, DONE = 3 };
 	int state = IDLE;
 	int path = 0, leaf_first = 0, leaf_count = 0, leaf_block = 0;
@@ -661,12 +664,12 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				// the L1 instead of four, the vector-memory path being this kernel's limit) straight into LDS
 				// (global_load_lds: destination = pass base + lane x 16, so the record of lane 4q + k lands
 				// contiguously at pass k, offset 64 q); every lane then reads its own record from LDS.
-				unsigned char* narea = reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * WF_GRP_WAVE_BYTES;
 				const int mine = state == DESCEND ? ts.curr : -1;
+				const uint32_t part16 = (uint32_t)(lane & 3) * 16u;   // 32-bit byte offsets from the uniform base: scalar-base addressing
 #define WF_NODE_PASS(K) { \
 					const int want = __builtin_amdgcn_mov_dpp(mine, (K) * 0x55, 0xf, 0xf, false);   /* quad_perm [K,K,K,K] */ \
 					if (want >= 0) \
-						__builtin_amdgcn_global_load_lds(nodes + 4 * (size_t)want + (lane & 3), (__attribute__((address_space(3))) void*)(narea + (K) * 1024), 16, 0, 0); \
+						__builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned char*>(nodes) + ((uint32_t)want * 64u + part16), (__attribute__((address_space(3))) void*)(uintptr_t)(nbase + (K) * 1024u), 16, 0, 0); \
 				}
 				WF_NODE_PASS(0) WF_NODE_PASS(1) WF_NODE_PASS(2) WF_NODE_PASS(3)
 #undef WF_NODE_PASS

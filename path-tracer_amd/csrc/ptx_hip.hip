@@ -468,6 +468,8 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 		}
 	}
 
+	// the traversal kernel addresses node records with 32-bit byte offsets from the array base
+	if (nodes.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu KD nodes; the limit is 2^26", nodes.size() / 4);
 	HIP_TRY(hipSetDevice(ctx->device));
 	PtxScene* s = new PtxScene();
 	s->device = ctx->device;
