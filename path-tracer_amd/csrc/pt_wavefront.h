@@ -163,7 +163,7 @@ PT_DEV bool leaf_only_mesh(const DevScene& sc, const DevObject& ob, const Ray& r
 }
 
 #ifndef WF_SEG_OCC
-#define WF_SEG_OCC 4
+#define WF_SEG_OCC 6
 #endif
 template <int FLAGS>
 __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevScene sc, DevCamera cam, WfParams wp) {
