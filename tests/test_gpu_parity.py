@@ -250,7 +250,7 @@ def _mesh_rays(desc, cam, orc, obj, rng, n_rand=6000):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["teapot", "lamborghini", "blender_comp"])
+@pytest.mark.parametrize("name", ["teapot", "lamborghini", "blender_comp", "blender_comp_open", "lamborghini_door"])
 def test_production_traversal_kernel_ray_by_ray(pt, orc, ctx, name):
     """ptx_trace_rays_queued: the wavefront pipeline's own traversal kernel (every leaf mode) against the oracle's
     rayIntersectsObject, ray by ray, on rays chosen to sit on triangle vertices / edges / box faces."""
