@@ -496,9 +496,10 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 #define WF_REFILL_MIN 8
 #endif
 // LDS staging area of leaf mode 5, per wave: 64 64-bit result keys (one per lane) and a list of
-// WF_UNIT_CAP 16-bit work units (owner lane | group << 6)
+// WF_UNIT_CAP 32-bit work units (owner lane | group << 6: 26 bits of group index, i.e. leaves of up to
+// 2^29 triangles, more than a scene may hold)
 #define WF_UNIT_CAP 320
-#define WF_GRP_WAVE_BYTES 4096   /* leaf phase: 64 * 8 + WF_UNIT_CAP * 2 = 1152 B; descent of mode 6: 64 node records */
+#define WF_GRP_WAVE_BYTES 4096   /* leaf phase: 64 * 8 + WF_UNIT_CAP * 4 = 1792 B; descent of mode 6: 64 node records */
 #define WF_GRP_BYTES ((PT_BLOCK / 64) * WF_GRP_WAVE_BYTES)
 
 PT_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			// wave works it off and carries on with the remaining groups.
 			unsigned char* area = reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * WF_GRP_WAVE_BYTES;
 			unsigned long long* keys = reinterpret_cast<unsigned long long*>(area);          // one result key per lane
-			unsigned short* units = reinterpret_cast<unsigned short*>(area + 64 * 8);
+			uint32_t* units = reinterpret_cast<uint32_t*>(area + 64 * 8);
 			const float4* __restrict__ gb = sc.grp_box;
 			const float4* __restrict__ tg = sc.tri_grp;
 			const unsigned long long lt = (1ull << lane) - 1ull;
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			for (int k = 0; k < 4; ++k) {
 				const bool on = (tb >> k) & 1u;
 				const unsigned long long tm = __ballot(on);
-				if (on) units[pending + (int)__popcll(tm & lt)] = (unsigned short)(lane | (k << 6));
+				if (on) units[pending + (int)__popcll(tm & lt)] = (uint32_t)lane | ((uint32_t)k << 6);
 				pending += (int)__popcll(tm);
 			}
 			int g = 4;       // per lane: next group of the own leaf beyond the first four
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 							touch = touches(bx[0], bx[1], ray.o, ray.inv);
 						}
 						const unsigned long long tm = __ballot(touch);
-						if (touch) units[nunits + (int)__popcll(tm & lt)] = (unsigned short)(lane | (g << 6));
+						if (touch) units[nunits + (int)__popcll(tm & lt)] = (uint32_t)lane | ((uint32_t)g << 6);
 						nunits += (int)__popcll(tm);
 						++g;
 					}

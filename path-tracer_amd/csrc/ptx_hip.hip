@@ -38,6 +38,7 @@ static void prof_clear(PtxCtx* c);
 
 struct PtxCtx {
 	int device;
+	int cus;              // hipDeviceProp_t::multiProcessorCount: sizes the persistent launches
 	hipStream_t stream;
 	bool has_render;
 	DevCamera cam;
@@ -155,9 +156,12 @@ extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 	if (n <= 0) return fail(PTX_E_NO_DEVICE, "no HIP device available (the product has no CPU path)");
 	if (device < 0 || device >= n) return fail(PTX_E_NO_DEVICE, "device %d out of range (%d devices)", device, n);
 	HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
 	PtxCtx* c = new PtxCtx();
 	memset(c, 0, sizeof(*c));
 	c->device = device;
+	c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
 	if (e != hipSuccess) { delete c; return fail(PTX_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
 	e = hipMalloc((void**)&c->d_stats, sizeof(PtxStats));
@@ -617,7 +621,7 @@ static int check_scene(const PtxCtx* ctx, const PtxScene* scene, const char* who
 
 // One traversal launch of the wavefront pipeline: the rays queued for multi-node mesh `obj` (queue k).
 static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams& wp, int obj, int k, int collect_stats) {
-	const int cus = 256;
+	const int cus = ctx->cus;
 	const size_t tb = (size_t)cus * (size_t)ctx->trav_blocks_per_cu; // persistent waves, each owns queue/waves entries
 	const size_t lds = stack_lds_bytes(scene);
 #define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
@@ -711,7 +715,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		batch >>= 1;
 	}
 	if (rc != PTX_OK) return rc;
-	const int cus = 256;
+	const int cus = ctx->cus;
 	const int maxb = ctx->cam.max_bounces;
 	for (int s0 = first_sample; s0 < first_sample + num_samples; s0 += batch) {
 		const int b = (first_sample + num_samples - s0) < batch ? (first_sample + num_samples - s0) : batch;

@@ -88,6 +88,19 @@ extern "C" int pth_log_lines(char* buf, int buf_len) {
 	return (int)all.size();
 }
 
+// distinct texture files of the loaded scene that failed to load: returns their number, writes them
+// newline-separated into buf (if given)
+extern "C" int pth_texture_failures(char* buf, int buf_len) {
+	const std::vector<std::string>& f = failedTextureFiles();
+	if (buf && buf_len > 0) {
+		std::string all;
+		for (size_t i = 0; i < f.size(); ++i) all += f[i] + "\n";
+		strncpy(buf, all.c_str(), (size_t)buf_len - 1);
+		buf[buf_len - 1] = 0;
+	}
+	return (int)f.size();
+}
+
 extern "C" PtxCtx* pth_context(void) { return kernelContext(); }
 
 extern "C" int pth_kernel_init(void) {

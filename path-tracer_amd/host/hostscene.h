@@ -43,3 +43,5 @@ struct HostSceneFlat {
 const HostSceneFlat& hostSceneFlat();
 void setDeviceUploadEnabled(bool on);
 int loadTexture(const std::string src_path);
+// texture files named by the loaded scene that could not be read (distinct paths, load order)
+const std::vector<std::string>& failedTextureFiles();

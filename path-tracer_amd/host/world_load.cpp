@@ -16,6 +16,7 @@
 #include "kernel.h"
 #include "objloader.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +37,10 @@ static std::vector<void*>& host_mem_ptrs = *new std::vector<void*>();
 static std::vector<KDNode*>& host_kdtrees = *new std::vector<KDNode*>();
 static std::vector<HostTexture>& host_textures = *new std::vector<HostTexture>();
 static std::map<std::string, int>& texture_by_path = *new std::map<std::string, int>();
+// distinct texture files the CURRENT scene names but that could not be loaded (bench.py checks them
+// against the files the reference tree itself lacks, .MISSING_LARGE_BLOBS)
+static std::vector<std::string>& failed_textures = *new std::vector<std::string>();
+const std::vector<std::string>& failedTextureFiles() { return failed_textures; }
 static std::vector<WorldObject>& host_wobjects = *new std::vector<WorldObject>();
 static HostSceneFlat& flat_scene = *new HostSceneFlat();
 static PtxScene* device_scene = NULL;
@@ -201,6 +206,8 @@ static Material* loadMaterialsToHost(const ObjScene& oscene) {
 				// printed once per file and process: lp560.mtl names 19 absent TGAs from 41 materials
 				static std::map<std::string, int>* warned = new std::map<std::string, int>();
 				if ((*warned)[*texture_path]++ == 0) printf("    Warning: texture load failed: %s\n", texture_path->c_str());
+				if (std::find(failed_textures.begin(), failed_textures.end(), *texture_path) == failed_textures.end())
+					failed_textures.push_back(*texture_path);
 				REPORT(warning("    Warning: texture load failed: %s", texture_path->c_str()));
 			}
 		}
@@ -488,6 +495,7 @@ void freeWorldObjects() {
 	host_mem_ptrs.clear();
 	host_textures.clear();
 	texture_by_path.clear();
+	failed_textures.clear();
 	host_wobjects.clear();
 	flat_scene = HostSceneFlat();
 	freeWorldObjSources();

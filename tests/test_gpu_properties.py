@@ -202,6 +202,63 @@ def test_fat_leaves_match_oracle(pt, orc, ctx, tmp_path):
         assert np.array_equal(ho[k], hg[k]), k
 
 
+def test_leaf_beyond_8192_triangles_matches_oracle(pt, orc, ctx, tmp_path):
+    """A flat 96x96 sheet: the builder splits it once (x) and then keeps two leaves of 9216 triangles, i.e.
+    1152 groups of eight each. The work units of leaf modes 5/6 name (owner lane, group): with 16-bit units
+    groups >= 1024 wrapped and hits in the far part of such a leaf were lost. Through the production
+    traversal kernel ray by ray and through a render."""
+    g = 96
+    lines = ["mtllib big.mtl", "usemtl white.diff"]
+    for z in range(g + 1):
+        for x in range(g + 1):
+            lines.append(f"v {(x - g / 2) * 0.125} 0 {(z - g / 2) * 0.125}")
+    vid = lambda x, z: z * (g + 1) + x + 1
+    for z in range(g):
+        for x in range(g):
+            lines.append(f"f {vid(x, z)} {vid(x + 1, z + 1)} {vid(x + 1, z)}")
+            lines.append(f"f {vid(x, z)} {vid(x, z + 1)} {vid(x + 1, z + 1)}")
+    (tmp_path / "big.obj").write_text("\n".join(lines) + "\n")
+    (tmp_path / "big.mtl").write_text("newmtl white.diff\nKd 0.8 0.8 0.8\n")
+    (tmp_path / "s.json").write_text(
+        '{"camera": {"pixelWidth": 48, "pixelHeight": 32, "direction": [0,-0.5,-1], "up": [0,1,0], "position": [0,6,12],'
+        ' "screenDist": 1.5, "screenHeight": 2}, "objects": ['
+        '{"type": "sphere", "render": true, "radius": 4, "position": [0, 12, 0], "material": {"type": "lumi", "Kd": [1], "Ke": [6]}},'
+        '{"type": "mesh", "render": true, "src": "%s"}]}' % (tmp_path / "big.obj"))
+    desc, cam = pt.load_scene(str(tmp_path / "s.json"))
+    d = desc.contents
+    leaf_sizes = sorted(d.nodes[i].num_tris for i in range(d.num_nodes) if d.nodes[i].left == -1 and d.nodes[i].right == -1)
+    assert leaf_sizes[-1] > 8192 + 8, leaf_sizes
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    # rays aimed at every part of the sheet, so that hits fall into groups on both sides of index 1024
+    rng = np.random.default_rng(5)
+    n = 6000
+    tgt = np.stack([rng.uniform(-5.9, 5.9, n), np.zeros(n), rng.uniform(-5.9, 5.9, n)], axis=1)
+    o = np.tile(np.array([[0.3, 7.0, 0.2]]), (n, 1)) + rng.normal(0, 0.5, (n, 3))
+    dd = tgt - o
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    o, dd = o.astype(np.float32), dd.astype(np.float32)
+    ho = orc.trace(desc, o, dd, 1)
+    assert (ho["hit"] == 1).sum() > 0.95 * n
+    # the hit triangles' positions in their leaf run reach beyond group 1024
+    prims = ho["prim"][ho["hit"] == 1].astype(np.int64)
+    assert prims.max() - prims.min() > 2 * 8192
+    try:
+        for variant in (0, 11, 7):
+            _tune(pt, ctx, b"trav_variant", variant)
+            hq = gpuops.trace_queued(ctx, scene, o, dd, 1)
+            for k in ("object", "prim", "t_bits", "bary"):
+                assert np.array_equal(ho[k], hq[k]), (variant, k)
+    finally:
+        _tune(pt, ctx, b"trav_variant", -1)
+    acc_o, st_o = orc.render(desc, cam, 0, 2, 6)
+    acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 2, 6, stats=True)
+    assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32))
+    assert (st_o.rays, st_o.n_tri, st_o.hit_mesh) == (st_g.rays, st_g.n_tri, st_g.hit_mesh)
+    acc_f, _ = gpuops.render(ctx, scene, cam, 0, 2, 6)
+    assert np.array_equal(acc_o.view(np.uint32), acc_f.view(np.uint32))
+
+
 def _many_mesh_scene(tmp_path, n_meshes, tris_per_mesh=48):
     """n_meshes multi-node meshes (random small triangles, > 33 each so the KD build splits them), partly
     overlapping in space so that closest-hit decisions cross object boundaries, plus a light."""
