@@ -43,11 +43,26 @@ def _worker(rank, world, port, out_dir):
         a = accum.numpy()
         orc.render(desc, cam, first, count, 77, accum=a, nthreads=2)
 
-    mine = sp.render_split(render_fn, accum, total_samples=6)
+    synced = []
+    mine = sp.render_split(render_fn, accum, total_samples=6, sync_fn=lambda: synced.append(1))
+    assert synced == [1]                       # the sync hook runs between the render and the collective
     partial = torch.zeros_like(accum)
     orc.render(desc, cam, mine[0], mine[1], 77, accum=partial.numpy(), nthreads=2)
     np.save(os.path.join(out_dir, f"partial{rank}.npy"), partial.numpy())
     np.save(os.path.join(out_dir, f"sum{rank}.npy"), accum.numpy())
+    # progressive: rounds of 4 global samples, a reduced copy after each; the local buffer keeps only this rank's samples
+    accum2 = torch.zeros_like(accum)
+    frames = []
+
+    def render_fn2(first, count):
+        orc.render(desc, cam, first, count, 77, accum=accum2.numpy(), nthreads=2)
+
+    last = sp.render_progressive(render_fn2, accum2, total_samples=6, every=4,
+                                 on_image=lambda img, done: frames.append((done, img.clone())))
+    assert [d for d, _ in frames] == [4, 6] and torch.equal(frames[-1][1], last)
+    np.save(os.path.join(out_dir, f"prog4_{rank}.npy"), frames[0][1].numpy())
+    np.save(os.path.join(out_dir, f"prog6_{rank}.npy"), last.numpy())
+    np.save(os.path.join(out_dir, f"proglocal{rank}.npy"), accum2.numpy())
     dist.destroy_process_group()
 
 
@@ -62,4 +77,10 @@ def test_two_rank_split_matches_single_rank(tmp_path, pt, orc):
     full, _ = orc.render(desc, cam, 0, 6, 77)
     # same sample set; only the float summation order differs ((s0+s1+s2)+(s3+s4+s5) vs sequential)
     assert np.allclose(s0, full, rtol=1e-5, atol=1e-6)
-    assert np.abs(s0 - full).max() > 0 or True
+    # progressive rounds: after round 1 every rank holds samples [0, 4), after round 2 all six
+    first4, _ = orc.render(desc, cam, 0, 4, 77)
+    for r in (0, 1):
+        assert np.allclose(np.load(tmp_path / f"prog4_{r}.npy"), first4, rtol=1e-5, atol=1e-6)
+        assert np.allclose(np.load(tmp_path / f"prog6_{r}.npy"), full, rtol=1e-5, atol=1e-6)
+    # the local buffers stayed partial: they sum to the final image exactly
+    assert np.array_equal(np.load(tmp_path / "proglocal0.npy") + np.load(tmp_path / "proglocal1.npy"), np.load(tmp_path / "prog6_0.npy"))
