@@ -148,6 +148,11 @@ typedef struct PtxStats {
 	 * per phase: diag0 = commit + refill, diag1 = descent, diag2 = leaf phase, diag3 = the part of diag2
 	 * spent in the unit steps of leaf mode 5 (tools/phase_clock.py prints the shares) */
 	uint64_t diag0, diag1, diag2, diag3;
+	/* what the unified traversal kernel (pt_unified.h) EXECUTED, counting variant only; bench.py's roofline is
+	 * built on these: wave iterations of the item loop, lanes holding an item in them (node / leaf-half records
+	 * fetched and box-tested), of which leaf halves, lanes waiting for their units in them, unit steps (16 groups
+	 * each), groups tested, unit phases, commit / refill turns */
+	uint64_t x_iters, x_item_lanes, x_half_lanes, x_wait_lanes, x_unit_steps, x_units, x_unit_phases, x_turns;
 } PtxStats;
 
 /* BSDF known-answer entry (parity for surfaces.cuh). */

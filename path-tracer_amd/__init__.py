@@ -78,7 +78,9 @@ class PtxStats(C.Structure):
                                           "hit_mesh", "hit_sphere", "hit_textured",
                                           "lane_steps_active", "lane_steps_total",
                                           "trav_rays", "trav_inner", "trav_box", "trav_tri", "trav_leaf",
-                                          "diag0", "diag1", "diag2", "diag3")]
+                                          "diag0", "diag1", "diag2", "diag3",
+                                          "x_iters", "x_item_lanes", "x_half_lanes", "x_wait_lanes", "x_unit_steps", "x_units",
+                                          "x_unit_phases", "x_turns")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

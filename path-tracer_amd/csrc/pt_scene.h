@@ -48,6 +48,10 @@
 //                  (X[l], X[l+4], Y[l], Y[l+4]) for the tri_pair component pairs; plane 4 carries in
 //                  .z/.w the triangles' slots in the UNSORTED run (int), which is what a hit reports and
 //                  what breaks ties between equal t (the reference tests a leaf in run order).
+//              The group boxes are stored a second time as LEAF-HALF RECORDS behind the node records of
+//              `nodes` (index half_base + 2 * block + h = groups 2h, 2h + 1 of that 32-triangle block), in the
+//              layout of an inner node's two child boxes, so that the unified traversal kernel tests a
+//              leaf's groups with the same fetch and the same packed box test as an inner step.
 //   tri_shade  4 x float4 per triangle (64 B), same order, touched once per mesh hit:
 //                s0 = (na.xyz, ta.x) s1 = (nb.xyz, ta.y) s2 = (nc.xyz, tb.x)
 //                s3 = (tb.y, tc.x, tc.y, int material_global_idx)
@@ -96,6 +100,7 @@ struct DevScene {
 	int32_t num_objects;
 	int32_t stack_entries;  // LDS traversal-stack slots per lane (>= deepest tree level, >= 1)
 	int32_t num_tris;       // triangles in tri_geom / per plane of tri_soa
+	int32_t half_base;      // index of the first leaf-half record in `nodes` (behind all node records)
 };
 
 struct DevCamera {

@@ -2,7 +2,7 @@
 // Host side of the library: argument validation, the packed scene upload, launches.
 // There is no CPU fallback anywhere in this file: without a HIP device every compute
 // entry point returns an error.
-#include "pt_wavefront.h"
+#include "pt_unified.h"
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -472,8 +472,27 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 		}
 	}
 
-	// the traversal kernel addresses node records with 32-bit byte offsets from the array base
-	if (nodes.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu KD nodes; the limit is 2^26", nodes.size() / 4);
+	// Leaf-half records (pt_scene.h): the group boxes of every 32-triangle block once more, two per record
+	// in the layout of an inner node's child boxes, appended to the node array so that the unified traversal
+	// kernel fetches and tests them with the code path of an inner step. Record half_base + 2 * block + h
+	// holds groups 2h and 2h + 1 of that block.
+	const size_t half_base = nodes.size() / 4;
+	{
+		const size_t nblocks_all = grp_boxes.size() / 8;
+		nodes.resize(nodes.size() + nblocks_all * 2 * 4, make_float4(0, 0, 0, 0));
+		for (size_t b = 0; b < nblocks_all; ++b)
+			for (int h = 0; h < 2; ++h) {
+				const float4 llo = grp_boxes[(4 * b + 2 * h) * 2], lhi = grp_boxes[(4 * b + 2 * h) * 2 + 1];
+				const float4 rlo = grp_boxes[(4 * b + 2 * h + 1) * 2], rhi = grp_boxes[(4 * b + 2 * h + 1) * 2 + 1];
+				float4* rec = &nodes[(half_base + 2 * b + (size_t)h) * 4];
+				rec[0] = make_float4(llo.x, rlo.x, llo.y, rlo.y);
+				rec[1] = make_float4(llo.z, rlo.z, lhi.x, rhi.x);
+				rec[2] = make_float4(lhi.y, rhi.y, lhi.z, rhi.z);
+				rec[3] = make_float4(0, 0, 0, 0);
+			}
+	}
+	// the traversal kernels address node / leaf-half records with 32-bit byte offsets from the array base
+	if (nodes.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu KD node and leaf-half records; the limit is 2^26", nodes.size() / 4);
 	HIP_TRY(hipSetDevice(ctx->device));
 	PtxScene* s = new PtxScene();
 	s->device = ctx->device;
@@ -529,6 +548,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	if ((rc = upload_vec(ctx, s, texs, &s->dev.textures)) != PTX_OK) { free_scene_allocs(s); delete s; return rc; }
 	s->dev.num_objects = d->num_objects;
 	s->dev.stack_entries = scene_max_depth < 1 ? 1 : scene_max_depth;
+	s->dev.half_base = (int32_t)half_base;
 	hipError_t e = hipStreamSynchronize(ctx->stream); // host vectors die at return
 	if (e != hipSuccess) { free_scene_allocs(s); delete s; return fail(PTX_E_HIP, "scene upload: %s", hipGetErrorString(e)); }
 	*out = s;
@@ -642,10 +662,14 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
 	//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
 	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3090)   11: mode 5 (3150)
+#define UNI(F, O, C, U) hipLaunchKernelGGL((wf_traverse_unified_kernel<F, O, C, U>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + WF_UNI_BYTES, ctx->stream, scene->dev, wp, obj, k)
+	//   12: unified item loop (pt_unified.h): descent and group boxes in one loop, units tested once 16 have gathered
+	const bool uni_fits = lds + WF_UNI_BYTES <= 64 * 1024;
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
 	if (collect_stats) {
-		if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
+		if (ctx->trav_variant == 12 && uni_fits) UNI(PT_F_STATS, 5, 128, 16);
+		else if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
 		else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
 		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
 		else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
@@ -662,6 +686,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
 		case 10: if (grp_fits) COOP(0, 4, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
 		case 11: if (grp_fits) COOP(0, 4, 128, 28, 5); else COOP(0, 4, 64, 32, 3); break;
+		case 12: if (uni_fits) UNI(0, 5, 128, 16); else COOP(0, 4, 64, 32, 3); break;
 		default:
 			if (grp_fits) COOP(0, 4, 128, 28, 6);
 			else if (stage_fits) COOP(0, 5, 64, 32, 4);
@@ -670,6 +695,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	}
 #undef TRAV
 #undef COOP
+#undef UNI
 }
 
 extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
