@@ -10,14 +10,20 @@ buffer) are resident in HBM before the timed region. With N > 1 (torchrun, one r
 every rank renders its own disjoint sample range per step (weak scaling, no data-path
 collective) and ONE all-reduce (RCCL) of the float accumulation buffers closes the timed region.
 
+The timed region ends when the accumulated buffer is resident on rank 0's HOST.
+
 Prints one JSON line (rank 0) with the contract fields plus
   "roofline"      for the dominant kernel, wf_traverse_coop_kernel (KD traversal + ray/triangle tests of
-                  the rays queued for a multi-node mesh): algorithmic bytes per launch (DESIGN.md
-                  "bytes per traversal"; counters measured on the SAME samples by the counting
-                  variant) / mean launch duration from HIP event pairs recorded around every launch
-                  of the timed region on the library's stream (ptx_profile_enable / ptx_profile_get)
+                  the rays queued for a multi-node mesh). Neither HBM nor MFMA bounds it (the 21 MB tree
+                  is cache-resident, nothing is a dense contraction), so `bound` names the unit that
+                  does: the larger of the vector-memory front end (texture-addresser busy) and VALU
+                  issue, from the committed PMC passes (profiles/r02_pmc.json, recomputable from them
+                  and profiles/r02_kernel_stats.csv alone) rescaled to the launch time measured live
+                  here with HIP event pairs on the library's stream. `executed` = bytes and flops the
+                  kernel really requests / computes, counted live on the same samples by its counting
+                  twin; `logical` = the reference algorithm's figures of SURVEY.md 8(d), a side field.
   "cpu_baseline"  the CPU oracle (a straight multithreaded port, oracle/) timed on this box's host
-                  cores on a bounded sample of the same workload.
+                  cores on a bounded sample of the same workload (+ a 1-thread figure).
 """
 import argparse
 import ctypes as C
@@ -35,30 +41,41 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def traverse_bytes_and_flops(st):
-    """Algorithmic bytes / flops of the traversal kernel: the traversal terms of SURVEY.md 8(d)'s
-    bytes_per_ray / flops_per_ray (DESIGN.md "Roofline").
+L2_PEAK_GBS = 34500.0       # MI355X_MICROARCH.md: L2 (per XCD, aggregate) ~34.5 TB/s
+PEAK_CLOCK_GHZ = 2.4        # MI355X_MICROARCH.md: max clock
+CUS, SIMDS = 256, 1024
+PMC_FILE = os.path.join("profiles", "r02_pmc.json")
 
-    per inner-node step: two child boxes (48 B) + two child indices (8 B)             = 56 B
-    per triangle test:   leaf index entry (4 B) + a, e1, e2 (36 B)                     = 40 B
-    per queued ray:      ray state in / closest-hit record out                         = 64 B
-    flops: 22 per box test, 48 per triangle test (Moeller-Trumbore incl. the division).
-    """
+
+def logical_bytes_and_flops(st):
+    """The REFERENCE algorithm's traversal terms of SURVEY.md 8(d) (a side field since round 2: the kernel does
+    not execute them): 56 B per inner step, 40 B per triangle test of its leaves, 64 B per queued ray;
+    22 flop per box test, 48 per triangle test."""
     b = 56 * st["trav_inner"] + 40 * st["trav_tri"] + 64 * st["trav_rays"]
     f = 22 * st["trav_box"] + 48 * st["trav_tri"]
     return b, f
 
 
-def load_traffic(workload_key):
-    """HBM bytes per wf_traverse_kernel launch from the committed PMC passes (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_wavefront_hbm_traffic.json")
+def executed_bytes_and_flops(st):
+    """What the traversal kernel itself requests and computes (counting twin of the default kernel, PtxStats.x_*):
+    a 64-B node record and one packed two-box test per descending lane and iteration; the four group boxes of a
+    leaf (128 B, four slab tests) per leaf visit; 320 B and eight triangle tests per work unit; per traversal the
+    queue entry, ray state in and the closest-hit record out (64 B)."""
+    b = 64 * st["x_item_lanes"] + 128 * st["x_half_lanes"] + 320 * st["x_units"] + 64 * st["trav_rays"]
+    f = 22 * (2 * st["x_item_lanes"] + 4 * st["x_half_lanes"]) + 48 * 8 * st["x_units"]
+    return b, f
+
+
+def load_pmc(kernel_prefix):
+    """Counter sums and derived fractions of the committed PMC passes (tools/profile_r02.sh) for one kernel."""
     try:
-        with open(path) as fh:
+        with open(os.path.join(ROOT, PMC_FILE)) as fh:
             d = json.load(fh)
-        if d.get("workload") == workload_key:
-            return d.get("traverse_hbm_bytes_per_launch")
     except (OSError, ValueError):
-        pass
+        return None
+    for name, e in d.get("kernels", {}).items():
+        if name.replace(" ", "").startswith(kernel_prefix.replace(" ", "")):
+            return e
     return None
 
 
@@ -189,7 +206,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline leg (rank 0): counters of the SAME samples from the counting variant --------------
+    # ---- roofline leg (rank 0): counters of the SAME samples from the counting twin of the default kernel -------
     pt.check(L.ptx_stats_reset(ctx))
     for i in range(args.warmup, args.warmup + args.steps):
         pt.check(L.ptx_render_samples(ctx, scene, (i * world + rank) * spp, spp, args.seed, 1))
@@ -197,35 +214,78 @@ def main():
     cst = pt.PtxStats()
     pt.check(L.ptx_stats_get(ctx, C.byref(cst)))
     cd = cst.as_dict()
-    b_total, f_total = traverse_bytes_and_flops(cd)
     n_launch = max(1, trav_n.value)
-    launch_ms = float(trav_ms.value) / n_launch
-    b_launch = b_total / n_launch
-    achieved_gbs = b_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    achieved_tflops = f_total / n_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+    launch_ms = float(trav_ms.value) / n_launch          # HIP event pairs around every launch of the timed region
+    launch_s = launch_ms * 1e-3
     tr = max(1, cd["trav_rays"])
-    workload_key = f"{args.scene}:{cam.width}x{cam.height}:spp{spp}:tex{args.textures}"
+    kernel = "wf_traverse_coop_kernel<0,4,128,28,6>"
+    xb, xf = executed_bytes_and_flops(cd)
+    lb, lf = logical_bytes_and_flops(cd)
+    x_tflops = xf / n_launch / launch_s / 1e12 if launch_s > 0 else 0.0
+    x_gbs = xb / n_launch / launch_s / 1e9 if launch_s > 0 else 0.0
+    pmc = load_pmc(kernel)
+    bound, achieved, peak, unit, frac, traffic, pmc_view = "valu", x_tflops, VALU_PEAK_TFLOPS, "TFLOP/s", x_tflops / VALU_PEAK_TFLOPS, None, None
+    if pmc and pmc.get("derived", {}).get("ta_busy_frac") and pmc.get("avg_ns_kernel_trace"):
+        d, c, nd = pmc["derived"], pmc["counters"], pmc["dispatches"]
+        # Which unit binds: the larger of the vector-memory front end (texture addresser busy) and VALU issue at
+        # the guide's 2 cycles per wave64 instruction. The counters are the committed profile's; the launch time
+        # is this run's, so each fraction is rescaled by profile launch time / live launch time.
+        scale = pmc["avg_ns_kernel_trace"] * 1e-6 / launch_ms if launch_ms > 0 else 1.0
+        ta = d["ta_busy_frac"] * scale
+        valu2 = d.get("valu_issue_frac_2cyc", 0.0) * scale
+        clock = d.get("clock_ghz", PEAK_CLOCK_GHZ)
+        traffic = round(d["hbm_side_bytes_per_launch"]) if "hbm_side_bytes_per_launch" in d else None
+        if ta >= valu2:
+            bound, unit = "vmem", "Gcycle/s busy, summed over the 256 texture addressers (one per CU)"
+            achieved = c["TA_TA_BUSY_sum"] / nd / launch_s / 1e9
+            peak = CUS * clock
+        else:
+            bound, unit = "valu-issue", "G wave64 VALU instructions/s"
+            achieved = c["SQ_INSTS_VALU"] / nd / launch_s / 1e9
+            peak = SIMDS * clock / 2.0
+        frac = achieved / peak
+        l2_gbs = c.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0 / nd / launch_s / 1e9
+        pmc_view = {
+            "source": PMC_FILE + " + profiles/r02_kernel_stats.csv (tools/profile_r02.sh; launch time there "
+                      f"{pmc['avg_ns_kernel_trace'] * 1e-6:.3f} ms, here {launch_ms:.3f} ms)",
+            "clock_ghz": round(clock, 3),
+            "ta_busy_frac": round(ta, 4),
+            "valu_issue_frac_2cyc_per_inst": round(valu2, 4),
+            "valu_issue_frac_4cyc_per_inst": round(d.get("valu_issue_frac_4cyc", 0.0) * scale, 4),
+            "active_lanes_per_valu_inst": round(d.get("active_lanes_per_valu_inst", 0.0), 2),
+            "valu_useful_frac": round(valu2 * d.get("active_lanes_per_valu_inst", 0.0) / 64.0, 4),
+            "l1_to_l2_read": {"achieved": round(l2_gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2_gbs / L2_PEAK_GBS, 4)},
+            "l1_tag_lookups_per_traversal": round(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / nd / max(1.0, cd["trav_rays"] / n_launch), 1),
+            "vmem_wave_instructions_per_64_traversals": round((c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0)) / nd / max(1.0, cd["trav_rays"] / n_launch) * 64.0, 1),
+            "l2_hit_frac": round(d.get("l2_hit_frac", 0.0), 4),
+            "wave_time_waiting_frac": round(d.get("wave_time_waiting_frac", 0.0), 4),
+        }
     roofline = {
-        "kernel": "wf_traverse_coop_kernel<0,4,128,28,6>", "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": load_traffic(workload_key),
-        "launch_ms": round(launch_ms, 4), "launches": trav_n.value, "bytes_per_launch": round(b_launch),
-        "traversals_per_launch": round(cd["trav_rays"] / n_launch), "bytes_per_traversal": round(b_total / tr, 1),
+        "kernel": kernel, "bound": bound, "achieved": round(achieved, 3), "peak": round(peak, 3), "unit": unit,
+        "frac": round(frac, 4), "traffic": traffic,
+        "launch_ms": round(launch_ms, 4), "launches": trav_n.value, "traversals_per_launch": round(cd["trav_rays"] / n_launch),
         "share_of_step": round(float(trav_ms.value) / max(1e-9, float(kernel_ms.value)), 4),
-        "valu": {"achieved": round(achieved_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(achieved_tflops / VALU_PEAK_TFLOPS, 5), "flops_per_traversal": round(f_total / tr, 1)},
-        "per_traversal": {k: round(cd[k] / tr, 3) for k in ("trav_inner", "trav_box", "trav_tri", "trav_leaf")},
-        # what the kernel itself reads: the group boxes inside the leaves (leaf mode 5/6) answer most of the
-        # reference's triangle tests without touching the triangles
-        "kernel_reads": {"triangle_slots_tested_per_traversal": round(max(0, cd["lane_steps_active"] - cd["trav_inner"]) / tr, 1),
-                         "bytes_per_traversal": round((64 * cd["trav_inner"] + 128 * cd["trav_leaf"] +
-                                                       40 * max(0, cd["lane_steps_active"] - cd["trav_inner"])) / tr + 64, 1)},
+        "timing": "HIP event pairs around every launch on the library's stream, inside the timed region (their cost is in value)",
+        "pmc": pmc_view,
+        # what the kernel executes, counted live on the same samples by its counting twin
+        "executed": {"bytes_per_traversal": round(xb / tr, 1), "flops_per_traversal": round(xf / tr, 1),
+                     "vmem": {"achieved": round(x_gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s requested of L1/L2", "frac": round(x_gbs / L2_PEAK_GBS, 4)},
+                     "valu": {"achieved": round(x_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(x_tflops / VALU_PEAK_TFLOPS, 4)},
+                     "per_traversal": {"node_records": round(cd["x_item_lanes"] / tr, 2), "leaf_visits_with_group_boxes": round(cd["x_half_lanes"] / tr, 2),
+                                       "work_units": round(cd["x_units"] / tr, 2), "triangle_slots_tested": round(8 * cd["x_units"] / tr, 1),
+                                       "descent_lanes_per_iteration": round(cd["x_item_lanes"] / max(1, cd["x_iters"]), 1),
+                                       "units_per_step": round(cd["x_units"] / max(1, cd["x_unit_steps"]), 1)}},
+        # the reference algorithm's own traffic and work on the same rays, which the kernel mostly avoids
+        "logical": {"bytes_per_traversal": round(lb / tr, 1), "flops_per_traversal": round(lf / tr, 1),
+                    "gbs": round(lb / n_launch / launch_s / 1e9, 1) if launch_s > 0 else 0.0,
+                    "tflops": round(lf / n_launch / launch_s / 1e12, 2) if launch_s > 0 else 0.0,
+                    "per_traversal": {k: round(cd[k] / tr, 3) for k in ("trav_inner", "trav_box", "trav_tri", "trav_leaf")}},
         "segment_kernel": {"launch_ms": round(float(seg_ms.value) / max(1, seg_n.value), 4), "launches": seg_n.value},
         "step_kernel_ms": round(float(kernel_ms.value) / args.steps, 3),
-        "note": "achieved = the ALGORITHMIC bytes of the reference traversal (56 B per inner step, 40 B per triangle test of "
-                "its leaves, 64 B per ray; SURVEY 8d) / launch time. It exceeds the HBM peak for two reasons: the tree and "
-                "triangle set are served by L1/L2/Infinity Cache (traffic = the measured L2-miss side), and the kernel "
-                "answers most of the reference's triangle tests from group boxes without reading the triangles "
-                "(kernel_reads). What binds is instruction issue and the vector-memory path (DESIGN.md, Roofline)",
+        "note": "bound = the unit with the highest utilisation in the committed PMC passes, rescaled to this run's launch time: "
+                "the vector-memory front end (texture-addresser busy) against VALU issue at 2 cycles per wave64 instruction "
+                "(MI355X_MICROARCH.md). Not HBM: the 21 MB tree is cache-resident (traffic = measured L2-miss side per launch). "
+                "A sensitivity run agrees: one extra L1-hitting load per descent iteration costs 8 %, 20 extra VALU instructions 2 % (DESIGN.md 3.4)",
     }
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------

@@ -148,10 +148,13 @@ typedef struct PtxStats {
 	 * per phase: diag0 = commit + refill, diag1 = descent, diag2 = leaf phase, diag3 = the part of diag2
 	 * spent in the unit steps of leaf mode 5 (tools/phase_clock.py prints the shares) */
 	uint64_t diag0, diag1, diag2, diag3;
-	/* what the unified traversal kernel (pt_unified.h) EXECUTED, counting variant only; bench.py's roofline is
-	 * built on these: wave iterations of the item loop, lanes holding an item in them (node / leaf-half records
-	 * fetched and box-tested), of which leaf halves, lanes waiting for their units in them, unit steps (16 groups
-	 * each), groups tested, unit phases, commit / refill turns */
+	/* what the traversal kernel EXECUTED, counting variant only (bench.py's roofline is built on these):
+	 *   x_iters       wave iterations of the descent loop (unified kernel: of the item loop)
+	 *   x_item_lanes  lanes that fetched and box-tested a 64-B record in them (node records; unified: + leaf halves)
+	 *   x_half_lanes  cooperative kernel: lanes that fetched their leaf's four group boxes (128 B); unified: leaf-half records
+	 *   x_wait_lanes  unified kernel: lanes waiting for their units, summed over iterations
+	 *   x_unit_steps  steps of the unit phase (16 groups of eight triangles each), x_units the groups tested in them
+	 *   x_unit_phases rounds with a leaf phase (unified: unit phases), x_turns commit / refill turns */
 	uint64_t x_iters, x_item_lanes, x_half_lanes, x_wait_lanes, x_unit_steps, x_units, x_unit_phases, x_turns;
 } PtxStats;
 

@@ -332,13 +332,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_unified_kernel(DevS
 	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
 	if (FLAGS & PT_F_STATS) {
 		diag_flush(wp.stats, dg0, dg1, dg2, dg3);
-		uint64_t x[8] = {x_iters, x_item, x_half, x_wait, x_usteps, x_units, x_uphases, x_turns};
-		unsigned long long* dst = (unsigned long long*)&wp.stats->x_iters;
-#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const uint64_t v = wave_sum_u64(x[k]);
-			if (lane == 0 && v) atomicAdd(dst + k, (unsigned long long)v);
-		}
+		exec_flush(wp.stats, x_iters, x_item, x_half, x_wait, x_usteps, x_units, x_uphases, x_turns);
 	}
 #undef WFU_CLOCK
 }

@@ -138,6 +138,18 @@ PT_DEV void diag_flush(PtxStats* stats, uint64_t d0, uint64_t d1, uint64_t d2, u
 	}
 }
 
+// PtxStats.x_* (include/ptx_hip.h): what a traversal kernel executed
+PT_DEV void exec_flush(PtxStats* stats, uint64_t iters, uint64_t item, uint64_t half, uint64_t wait, uint64_t usteps, uint64_t units,
+                       uint64_t uphases, uint64_t turns) {
+	uint64_t x[8] = {iters, item, half, wait, usteps, units, uphases, turns};
+	unsigned long long* dst = (unsigned long long*)&stats->x_iters;
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const uint64_t v = wave_sum_u64(x[k]);
+		if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst + k, (unsigned long long)v);
+	}
+}
+
 // A single-leaf mesh (root is a leaf): all lanes walk the same triangle run, whose addresses are
 // wave-uniform, so the compiler can fetch the triangles with scalar loads.
 template <int FLAGS>
@@ -566,6 +578,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	const float4* __restrict__ pe2 = sc.tri_soa + 2 * (size_t)sc.num_tris;
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
 	uint64_t act = 0, tot = 0, n_taken = 0, dg0 = 0, dg1 = 0, dg2 = 0, dg3 = 0;
+	// what the kernel EXECUTES (PtxStats.x_*, bench.py's roofline): descent iterations, lanes descending in them,
+	// leaf lanes fetching group boxes, -, unit steps, units, rounds with a leaf phase, commit / refill turns
+	uint64_t x_iters = 0, x_item = 0, x_half = 0, x_usteps = 0, x_units = 0, x_uphases = 0, x_turns = 0;
 
 	WaveFeed feed;
 	feed.exhausted = CHUNK == 0;
@@ -625,6 +640,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 		// three traversals ending per round the whole wave would otherwise pay for this block every round.
 		const int n_wait = (int)__popcll(__ballot(state == DONE || state == IDLE));
 		const bool turn = n_wait >= WF_REFILL_MIN || n_wait == 64;
+		if (FLAGS & PT_F_STATS) { if (turn && lane == 0) x_turns++; }
 		if (turn && state == DONE) commit();
 		// ---- refill idle lanes from the wave's chunk ----
 		for (int attempt = 0; turn && attempt < 2; ++attempt) {
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 		for (int iter = 0; ; ++iter) {
 			const int n_desc = (int)__popcll(__ballot(state == DESCEND));
 			if (n_desc == 0 || (iter > 0 && n_desc <= ATHRESH)) break;
-			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64;  } }
+			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; x_iters++; } if (state == DESCEND) x_item++; }
 			if (FLAT == 6) {
 				// Leaf mode 6 = mode 5 + node records fetched by the QUAD: in pass k the four lanes of a quad
 				// read the four 16-B parts of the record lane 4q + k wants (one 64-B line: one tag lookup in
@@ -771,6 +787,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			const unsigned long long lt = (1ull << lane) - 1ull;
 			const bool isleaf = state == LEAF;
 			const int ngroups = isleaf ? (leaf_count + 7) >> 3 : 0;
+			if (FLAGS & PT_F_STATS) { if (lane == 0 && m != 0ull) x_uphases++; if (ngroups > 0) x_half++; }
 			// slab test of a group box on min/max (a NaN from 0 * inf drops out: that axis does not constrain)
 			auto touches = [](const float4 lo, const float4 hi, f3 o, f3 inv) {
 				const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
@@ -825,11 +842,13 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				__builtin_amdgcn_wave_barrier();
 				const unsigned long long c3 = WF_CLOCK();
 				// ---- work the list off: 16 units per step ----
+				if (FLAGS & PT_F_STATS) { if (lane == 0) x_units += (uint64_t)nunits; }
 				for (int s16 = 0; s16 < nunits; s16 += 16) {
 					const int ui = s16 + (lane >> 2);
 					const bool on = ui < nunits;
 					const uint32_t un = units[on ? ui : s16];
 					const int owner = (int)(un & 63u), grp = (int)(un >> 6);
+					if (FLAGS & PT_F_STATS) { if (lane == 0) x_usteps++; }
 					// the owner's ray and leaf come straight out of its registers (no LDS copy: the staging
 					// area stays small enough for one more wave per SIMD)
 					const f3 bo = mk3(__shfl(ray.o.x, owner, 64), __shfl(ray.o.y, owner, 64), __shfl(ray.o.z, owner, 64));
@@ -1170,7 +1189,10 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 		}
 	}
 	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
-	if (FLAGS & PT_F_STATS) diag_flush(wp.stats, dg0, dg1, dg2, dg3);
+	if (FLAGS & PT_F_STATS) {
+		diag_flush(wp.stats, dg0, dg1, dg2, dg3);
+		exec_flush(wp.stats, x_iters, x_item, x_half, 0, x_usteps, x_units, x_uphases, x_turns);
+	}
 #undef WF_CLOCK
 }
 

@@ -673,7 +673,8 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
 		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
 		else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
-		else COOP(PT_F_STATS, 4, 128, 28, 5);
+		else if (ctx->trav_variant == 10 || ctx->trav_variant == 11) COOP(PT_F_STATS, 4, 128, 28, 5);
+		else COOP(PT_F_STATS, 4, 128, 28, 6);   // the counting twin of the default kernel
 	} else switch (ctx->trav_variant) {
 		case 1: TRAV(0, 1, 3, 0); break;
 		case 2: TRAV(0, 1, 3, 64); break;
