@@ -171,7 +171,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_unified_kernel(DevS
 				wp.s0[path].w = d;
 				wp.s1[path].w = ts.tmin;
 				wp.s2[path].w = __int_as_float(obj_index);
-				wp.s3[path] = make_float4(__int_as_float(ts.tri), u_, v_, 0.0f);
+				store_hit(wp.s3 + path, ts.tri, u_, v_);
 			}
 		}
 		state = IDLE;

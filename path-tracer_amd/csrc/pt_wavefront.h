@@ -28,7 +28,13 @@
 //
 // Path state in HBM, 4 x float4 per path (64 B), SoA so lanes of a wave read consecutive 16-B words:
 //   s0 = (origin.xyz, best_dist)   s1 = (dir.xyz, best_t)
-//   s2 = (mask.rgb, int best_obj)  s3 = (int best_tri, bary_u, bary_v, -)
+//   s2 = (mask.rgb, int best_obj)  s3 = (int best_tri, bary_u, bary_v, int path id)
+// The state is COMPACTED at every bounce: there are two sets of these arrays, and the paths that survive
+// bounce b are written to set b & 1 at consecutive SLOTS (slot = position in that bounce's list of
+// survivors; the path id - sample-major, then 8x8 pixel tiles - travels in s3.w). Bounce b + 1 reads slots
+// 0 .. n-1 of that set densely, and the traversal queues hold slots. (Round 1 kept one set indexed by path id
+// plus live lists of ids: once two thirds of the paths had ended, every 16-B record read or written dragged a
+// 64-B line of dead neighbours along: 22 GB of HBM-side traffic per launch, profiles/r01_*, r02_pmc.json.)
 #pragma once
 #include "pt_kernels.h"
 
@@ -39,10 +45,10 @@
 #define PT_WF_MAX_BOUNCES 64
 
 struct WfParams {
-	float4* s0; float4* s1; float4* s2; float4* s3;
+	float4* s0; float4* s1; float4* s2; float4* s3;         // state set this bounce WRITES (and its traversals update)
+	const float4* i0; const float4* i1; const float4* i2; const float4* i3;   // state set of the previous bounce (read)
 	float4* rad;              // [batch][npix]
-	int* live[2];             // ping-pong live-path lists
-	int* queue[PT_MAX_BIG];   // per multi-node mesh: path ids whose ray enters its root box
+	int* queue[PT_MAX_BIG];   // per multi-node mesh: slots (in s0..s3) of the paths whose ray enters its root box
 	int* counters;            // [bounce][1 + PT_MAX_BIG]: live count, queue counts (zeroed per batch)
 	PtxStats* stats;
 	int first_sample, batch;
@@ -138,6 +144,14 @@ PT_DEV void diag_flush(PtxStats* stats, uint64_t d0, uint64_t d1, uint64_t d2, u
 	}
 }
 
+// A traversal's result goes into the first three words of the path's s3 record; the fourth carries the path id
+// (written by the segment kernel) and must survive: one 12-byte store.
+struct HitWords { int tri; float u, v; };
+PT_DEV void store_hit(float4* rec, int tri, float u, float v) {
+	HitWords h; h.tri = tri; h.u = u; h.v = v;
+	*reinterpret_cast<HitWords*>(rec) = h;
+}
+
 // PtxStats.x_* (include/ptx_hip.h): what a traversal kernel executed
 PT_DEV void exec_flush(PtxStats* stats, uint64_t iters, uint64_t item, uint64_t half, uint64_t wait, uint64_t usteps, uint64_t units,
                        uint64_t uphases, uint64_t turns) {
@@ -182,8 +196,6 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int bounce = wp.bounce;
 	const int n_in = bounce == 0 ? wp.n_total : WF_CNT(wp, bounce - 1, 0);
-	const int* __restrict__ live_in = wp.live[(bounce & 1) ^ 1];
-	int* __restrict__ live_out = wp.live[bounce & 1];
 	const f3 cam_pos = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
 
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
@@ -215,7 +227,15 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 		const int i = blk0 + round * PT_BLOCK + tid;
 		bool alive = i < n_in;
 		int path = 0;
-		if (alive) path = bounce == 0 ? i : live_in[i];
+		float4 a0, a1, a2, a3;
+		if (alive) {
+			if (bounce == 0) path = i;
+			else {
+				// slot i of the previous bounce's compacted state: dense, coalesced reads
+				a0 = wp.i0[i]; a1 = wp.i1[i]; a2 = wp.i2[i]; a3 = wp.i3[i];
+				path = __float_as_int(a3.w);
+			}
+		}
 		// path id -> (sample, pixel): sample-major, then 8x8 tiles, lane = x + 8 y inside the tile
 		const int sl = path / wp.npt, r = path - sl * wp.npt;
 		const int tile = r >> 6, l = r & 63;
@@ -240,7 +260,6 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 				}
 			} else {
 				// ---- resolve the closest hit of the previous segment and shade it ------------------
-				const float4 a0 = wp.s0[path], a1 = wp.s1[path], a2 = wp.s2[path], a3 = wp.s3[path];
 				init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
 				mask = mk3(a2.x, a2.y, a2.z);
 				const int best_obj = __float_as_int(a2.w);
@@ -307,6 +326,11 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 		__syncthreads();
 		const int n_live = sh_n;
 		const int n_chunks = (n_live + PT_BLOCK - 1) / PT_BLOCK;
+		// every compacted ray survives phase 2, so the block's slot range in this bounce's state set (= its part of
+		// the list of survivors) can be reserved now: ONE atomic per block and iteration
+		if (tid == 0) sh_base[0] = n_live ? atomicAdd(&WF_CNT(wp, bounce, 0), n_live) : 0;
+		__syncthreads();
+		const int base0 = sh_base[0];
 
 	// ---- phase 2: intersect the new segments with the cheap objects, enqueue them for the expensive ones ----
 	for (int chunk = 0; chunk < n_chunks; ++chunk) {
@@ -359,20 +383,20 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 			}
 		}
 		if (alive) {
-			wp.s0[path] = make_float4(ray.o.x, ray.o.y, ray.o.z, best_dist);
-			wp.s1[path] = make_float4(ray.d.x, ray.d.y, ray.d.z, best_t);
-			wp.s2[path] = make_float4(mask.x, mask.y, mask.z, __int_as_float(best_obj));
-			wp.s3[path] = make_float4(__int_as_float(best_tri), b_u, b_v, 0.0f);
-			flags |= 1u;
+			const int slot = base0 + k;
+			wp.s0[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, best_dist);
+			wp.s1[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, best_t);
+			wp.s2[slot] = make_float4(mask.x, mask.y, mask.z, __int_as_float(best_obj));
+			wp.s3[slot] = make_float4(__int_as_float(best_tri), b_u, b_v, __int_as_float(path));
 		}
 		sh_flags[chunk * PT_BLOCK + tid] = flags;
-		for (int L = 0; L < nlists; ++L) {
+		for (int L = 1; L < nlists; ++L) {
 			const unsigned long long m = __ballot((flags >> L) & 1u);
 			if (lane == 0) sh_cnt[L][chunk * (PT_BLOCK / 64) + wave] = (int)__popcll(m);
 		}
 	} // chunks
 		__syncthreads();
-		if (tid < nlists) {
+		if (tid >= 1 && tid < nlists) {   // list 0 (the survivors) was reserved before phase 2
 			int total = 0;
 			for (int j = 0; j < n_chunks * (PT_BLOCK / 64); ++j) {
 				const int c = sh_cnt[tid][j];
@@ -386,13 +410,12 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 		for (int chunk = 0; chunk < n_chunks; ++chunk) {
 			const int k = chunk * PT_BLOCK + tid;
 			const uint32_t f = sh_flags[k];
-			const int p = k < n_live ? sh_path[k] : 0;
-			for (int L = 0; L < nlists; ++L) {
+			for (int L = 1; L < nlists; ++L) {
 				const bool on = (f >> L) & 1u;
 				const unsigned long long m = __ballot(on);
 				if (on) {
-					const int slot = sh_base[L] + sh_cnt[L][chunk * (PT_BLOCK / 64) + wave] + (int)__popcll(m & ((1ull << lane) - 1ull));
-					if (L == 0) live_out[slot] = p; else wp.queue[L - 1][slot] = p;
+					const int qslot = sh_base[L] + sh_cnt[L][chunk * (PT_BLOCK / 64) + wave] + (int)__popcll(m & ((1ull << lane) - 1ull));
+					wp.queue[L - 1][qslot] = base0 + k;   // the ray's slot in this bounce's state set
 				}
 			}
 		}
@@ -478,7 +501,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 						wp.s0[path].w = d;
 						wp.s1[path].w = ts.tmin;
 						wp.s2[path].w = __int_as_float(obj_index);
-						wp.s3[path] = make_float4(__int_as_float(ts.tri), ts.bu, ts.bv, 0.0f);
+						store_hit(wp.s3 + path, ts.tri, ts.bu, ts.bv);
 					}
 				}
 				active = false;
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				wp.s0[path].w = d;
 				wp.s1[path].w = ts.tmin;
 				wp.s2[path].w = __int_as_float(obj_index);
-				wp.s3[path] = make_float4(__int_as_float(ts.tri), ts.bu, ts.bv, 0.0f);
+				store_hit(wp.s3 + path, ts.tri, ts.bu, ts.bv);
 			}
 		}
 		state = IDLE;

@@ -49,8 +49,10 @@ struct PtxCtx {
 	size_t pbo_pixels;
 	hipEvent_t ev0, ev1;
 	bool timer_open;
-	// wavefront pipeline buffers (allocated on first use, grown on demand)
+	// wavefront pipeline buffers (allocated on first use, grown on demand); wf.s0..s3 and wf_b[0..3] are the two
+	// sets of compacted path state (pt_wavefront.h), used in turn from bounce to bounce
 	WfParams wf;
+	float4* wf_b[4];
 	size_t wf_paths, wf_rad;   // capacities (paths, rad entries)
 	int wf_queues;
 	int wf_batch;              // samples per wavefront pass
@@ -118,7 +120,8 @@ static Tuning tuning_defaults() {
 	Tuning t;
 	// samples per pass: large queues amortise the ramp/tail of the persistent traversal launches
 	// (8 -> 64: 1274 -> 1601 Mrays/s with the first cooperative kernel; 64 -> 128 -> 256: 3278 -> 3377 -> 3426 now);
-	// costs 100 B of state per path: 26.5 GB at 1080p x 128 samples, capped at 2^28 paths per pass
+	// costs 148 B of state per path (two sets of 64 B, queue entry, parked radiance): 39 GB at 1080p x 128 samples,
+	// capped at 2^28 paths per pass
 	t.wf_batch = clampi(env_int("PTX_WF_BATCH", 128), 1, 256);
 	t.force_megakernel = env_int("PTX_MEGAKERNEL", 0) != 0;
 	t.trav_variant = env_int("PTX_TRAV_VARIANT", 0);
@@ -177,12 +180,13 @@ extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 extern "C" int ptx_render_cleanup(PtxCtx* ctx);
 
 static void wf_free(PtxCtx* c) {
-	void* ptrs[] = {c->wf.s0, c->wf.s1, c->wf.s2, c->wf.s3, c->wf.rad, c->wf.live[0], c->wf.live[1], c->wf.counters};
+	void* ptrs[] = {c->wf.s0, c->wf.s1, c->wf.s2, c->wf.s3, c->wf_b[0], c->wf_b[1], c->wf_b[2], c->wf_b[3], c->wf.rad, c->wf.counters};
 	for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i)
 		if (ptrs[i]) hipFree(ptrs[i]);
 	for (int k = 0; k < PT_MAX_BIG; ++k)
 		if (c->wf.queue[k]) hipFree(c->wf.queue[k]);
 	memset(&c->wf, 0, sizeof(c->wf));
+	memset(c->wf_b, 0, sizeof(c->wf_b));
 	c->wf_paths = c->wf_rad = 0;
 	c->wf_queues = 0;
 }
@@ -199,9 +203,8 @@ static int wf_ensure(PtxCtx* c, size_t paths, size_t rad, int queues) {
 	HIP_TRY(hipMalloc((void**)&c->wf.s1, paths * sizeof(float4)));
 	HIP_TRY(hipMalloc((void**)&c->wf.s2, paths * sizeof(float4)));
 	HIP_TRY(hipMalloc((void**)&c->wf.s3, paths * sizeof(float4)));
+	for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&c->wf_b[k], paths * sizeof(float4)));
 	HIP_TRY(hipMalloc((void**)&c->wf.rad, rad * sizeof(float4)));
-	HIP_TRY(hipMalloc((void**)&c->wf.live[0], paths * sizeof(int)));
-	HIP_TRY(hipMalloc((void**)&c->wf.live[1], paths * sizeof(int)));
 	for (int k = 0; k < queues; ++k) HIP_TRY(hipMalloc((void**)&c->wf.queue[k], paths * sizeof(int)));
 	HIP_TRY(hipMalloc((void**)&c->wf.counters, 2 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) * sizeof(int))); // counts + traversal cursors
 	c->wf_paths = paths;
@@ -732,7 +735,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	int batch = ctx->wf_batch;
 	while (batch > 1 && npt * (size_t)batch > ((size_t)1 << 28)) batch >>= 1;
 	if (batch > num_samples) batch = num_samples;
-	// 100 B of state per path: if the device cannot hold the preferred batch (other tenants, huge frames),
+	// 148 B of state per path: if the device cannot hold the preferred batch (other tenants, huge frames),
 	// halve it rather than fail; the result does not depend on the batch size
 	for (;;) {
 		rc = wf_ensure(ctx, (npt * (size_t)batch + WF_ROUNDS * PT_BLOCK), npix * (size_t)batch, scene->num_big);
@@ -760,6 +763,12 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		for (int bounce = 0; bounce <= maxb; ++bounce) {
 			wp.bounce = bounce;
 			wp.is_last = bounce == maxb ? 1 : 0;
+			// compacted state, two sets in turn: this bounce writes set (bounce & 1) and reads the other
+			float4* const set_a[4] = {ctx->wf.s0, ctx->wf.s1, ctx->wf.s2, ctx->wf.s3};
+			float4* const* out = (bounce & 1) ? ctx->wf_b : set_a;
+			float4* const* in = (bounce & 1) ? set_a : ctx->wf_b;
+			wp.s0 = out[0]; wp.s1 = out[1]; wp.s2 = out[2]; wp.s3 = out[3];
+			wp.i0 = in[0]; wp.i1 = in[1]; wp.i2 = in[2]; wp.i3 = in[3];
 			size_t blocks = ((size_t)wp.n_total + WF_ROUNDS * PT_BLOCK - 1) / (WF_ROUNDS * PT_BLOCK);
 			if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
 			prof_mark(ctx, 1);
