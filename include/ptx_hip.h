@@ -156,6 +156,10 @@ typedef struct PtxStats {
 	 *   x_unit_steps  steps of the unit phase (16 groups of eight triangles each), x_units the groups tested in them
 	 *   x_unit_phases rounds with a leaf phase (unified: unit phases), x_turns commit / refill turns */
 	uint64_t x_iters, x_item_lanes, x_half_lanes, x_wait_lanes, x_unit_steps, x_units, x_unit_phases, x_turns;
+	/* shading divergence in the segment kernel, counting variant only (the material-sorting question):
+	 * waves in which at least one lane shades a hit, the lanes that do, the BSDF branches (diffuse / specular /
+	 * transparent) those waves execute summed over waves, and lanes per material type 0..3 */
+	uint64_t sh_waves, sh_lanes, sh_branches, sh_type_lanes[4];
 } PtxStats;
 
 /* BSDF known-answer entry (parity for surfaces.cuh). */

@@ -189,7 +189,7 @@ PT_DEV bool leaf_only_mesh(const DevScene& sc, const DevObject& ob, const Ray& r
 }
 
 #ifndef WF_SEG_OCC
-#define WF_SEG_OCC 6
+#define WF_SEG_OCC 5   // 96 registers, 11 spilled values; at 6 waves/SIMD (80 registers) the compacted-state version spills 35: 7.40 vs 7.14 ms
 #endif
 template <int FLAGS>
 __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevScene sc, DevCamera cam, WfParams wp) {
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
 	uint64_t n_rays = 0, n_paths = 0, c_hm = 0, c_hs = 0, c_ht = 0;
+	uint64_t sh_waves = 0, sh_lanes = 0, sh_branches = 0, sh_t[4] = {0, 0, 0, 0};
 
 	// A workgroup takes WF_ROUNDS x 256 paths per iteration and works in two phases:
 	//   1. generate / shade: one path per lane; the rays that go on are COMPACTED into LDS
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 
 		Ray ray;
 		f3 mask = mk3(1.0f);
+		int shade_type = -1;   // counting variant: material type of the hit this lane shades
 		if (alive) {
 			if (bounce == 0) {
 				f3 mid, centre;
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 					if (FLAGS & PT_F_STATS) {
 						const MaterialRec mt = load_material(sc, hi.material);
 						if (cam.texture_enabled && mt.texture > -1 && hi.tri >= 0) c_ht++;
+						shade_type = mt.type;
 					}
 					const u4 rnd = philox4x32_10(pixel, sample, (uint32_t)(bounce - 1), 0u, wp.k0, wp.k1);
 					done = shade_segment(sc, cam, hi, ray, mask, rnd, out);
@@ -306,6 +309,16 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 					n_paths++;
 					alive = false;
 				}
+			}
+		}
+		if (FLAGS & PT_F_STATS) {
+			// shading divergence of this wave: which BSDF branches it had to run, for how many lanes
+			const unsigned long long sm = __ballot(shade_type >= 0);
+			if (sm != 0ull) {
+				const int nb = (__ballot(shade_type == 1) != 0ull) + (__ballot(shade_type == 2) != 0ull) + (__ballot(shade_type == 3) != 0ull);
+				if (lane == 0) { sh_waves++; sh_branches += (uint64_t)nb; }
+				if (shade_type >= 0) { sh_lanes++; }
+				if (shade_type == 0) sh_t[0]++; else if (shade_type == 1) sh_t[1]++; else if (shade_type == 2) sh_t[2]++; else if (shade_type == 3) sh_t[3]++;
 			}
 		}
 		// compact: slot = (LDS counter, one add per wave) + rank inside the wave
@@ -422,6 +435,15 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 		__syncthreads();
 	}
 	stats_flush(wp.stats, cnt, n_rays, n_paths, c_hm, c_hs, c_ht, 0, 0, (FLAGS & PT_F_STATS) != 0);
+	if (FLAGS & PT_F_STATS) {
+		uint64_t x[7] = {sh_waves, sh_lanes, sh_branches, sh_t[0], sh_t[1], sh_t[2], sh_t[3]};
+		unsigned long long* dst = (unsigned long long*)&wp.stats->sh_waves;
+#pragma unroll
+		for (int k = 0; k < 7; ++k) {
+			const uint64_t v = wave_sum_u64(x[k]);
+			if (lane == 0 && v) atomicAdd(dst + k, (unsigned long long)v);
+		}
+	}
 }
 
 // KD traversal of the rays queued for one multi-node mesh; merges into the path's closest-hit record.

@@ -424,3 +424,19 @@ def test_hand_built_deep_tree_uses_the_fallback_modes(pt, orc, ctx, D):
     finally:
         _tune(pt, ctx, b"trav_variant", -1)
         pt.lib().ptx_scene_free(ctx, scene)
+
+
+def test_shading_divergence_counters_are_consistent(pt, ctx):
+    """The counting variant's shading-divergence counters (PtxStats.sh_*, the evidence behind the material-sorting
+    decision in DESIGN.md): every shaded hit is counted once, under exactly one material type, and a shading
+    wave runs between 0 (light sources only) and 3 BSDF branches."""
+    desc, cam = pt.load_scene("geoms", width=128, height=96)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    _, st = gpuops.render(ctx, scene, cam, 0, 8, 4, stats=True)
+    d = st.as_dict()
+    assert d["sh_lanes"] == d["hit_mesh"] + d["hit_sphere"] > 0
+    assert sum(d[f"sh_type{k}"] for k in range(4)) == d["sh_lanes"]
+    assert d["sh_type1"] > 0 and d["sh_type2"] > 0 and d["sh_type3"] > 0 and d["sh_type0"] > 0   # geoms has all four
+    assert 0 < d["sh_waves"] <= d["sh_lanes"] and d["sh_branches"] <= 3 * d["sh_waves"]
+    assert d["sh_branches"] >= d["sh_waves"] * 0.5
