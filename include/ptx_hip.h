@@ -273,6 +273,13 @@ int ptx_radiance_sample(PtxCtx* ctx, const PtxScene* scene, int sample, uint64_t
  * and the bit pattern of the first that does (0xffffffff if none). */
 int ptx_selftest_rcp(PtxCtx* ctx, float lo, float hi, uint64_t* checked, uint64_t* mismatches, uint32_t* first_bad_bits);
 
+/* Device self-test: the float3 helpers every hot-path function is built from (reference:
+ * external/include/cutil_math.h:322-416 dot, cross, length, normalize, reflect, operator* / + - ) on n pairs
+ * (a, b) and scalars s, all on the host, 3 / 3 / 1 floats per case; out: 20 floats per case = dot(a,b),
+ * length(a), cross(a,b).xyz, normalize(a).xyz, reflect(a,b).xyz, (a*s).xyz, (a/s).xyz, (a+b).x, (a-b).x,
+ * (a*b).x. tests/ compares them bit for bit with the reference's own header compiled on the host (oracle/_ref). */
+int ptx_selftest_vec3(PtxCtx* ctx, int n, const float* a_host, const float* b_host, const float* s_host, float* out_host);
+
 #ifdef __cplusplus
 }
 #endif

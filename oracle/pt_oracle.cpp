@@ -555,6 +555,21 @@ extern "C" void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], 
 }
 
 // reference: src/cutility.cuh:7-15
+// The V3 helpers above on one pair (a, b) and scalar s, in the layout of oracle/ref_shim.cpp:ref_vec3_ops
+// (which runs the reference's own external/include/cutil_math.h): dot, length(a), cross, normalize(a),
+// reflect(a, b), a*s, a/s (= a * (1/s), cutil_math.h:348-352), (a+b).x, (a-b).x, (a*b).x
+extern "C" void orc_vec3_ops(const float* pa, const float* pb, float s, float* out) {
+	const V3 a = ld3(pa), b = ld3(pb);
+	const V3 c = cross(a, b), n = normalize(a), r = reflect(a, b), m = scale(a, s), q = scale(a, 1.0f / s);
+	out[0] = dot(a, b); out[1] = length(a);
+	out[2] = c.x; out[3] = c.y; out[4] = c.z;
+	out[5] = n.x; out[6] = n.y; out[7] = n.z;
+	out[8] = r.x; out[9] = r.y; out[10] = r.z;
+	out[11] = m.x; out[12] = m.y; out[13] = m.z;
+	out[14] = q.x; out[15] = q.y; out[16] = q.z;
+	out[17] = add(a, b).x; out[18] = sub(a, b).x; out[19] = mul(a, b).x;
+}
+
 extern "C" uint32_t orc_wang_hash(uint32_t seed) {
 	seed = (seed ^ 61) ^ (seed >> 16);
 	seed *= 9;

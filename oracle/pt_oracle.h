@@ -70,6 +70,7 @@ int orc_tonemap(const float* accum_rgba, int n_pixels, int iter, float gamma, un
 
 /* reference: src/cutility.cuh:7-15 wang_hash */
 uint32_t orc_wang_hash(uint32_t seed);
+void orc_vec3_ops(const float* a, const float* b, float s, float* out20);
 
 /* building blocks exposed for unit tests */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

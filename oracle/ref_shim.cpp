@@ -5,6 +5,8 @@
 #include "camera.h"      // reference: src/camera.h
 #include "jsonResolve.h" // reference: src/jsonResolve.h
 #include "utility.h"     // reference: src/utility.h
+#include "cutil_math.h"  // reference: external/include/cutil_math.h (float3 helpers of every hot-path function)
+#include "cutility.cuh"  // reference: src/cutility.cuh (wang_hash; its __device__ printf helpers compile as host code)
 #include <sstream>
 #include <string.h>
 
@@ -58,3 +60,20 @@ extern "C" int ref_resolve(const char* json_text, const char* key, float* f3out,
 	*mat_type = root[key].isString() ? (int)resolveMatType(root[key]) : -1;
 	return 0;
 }
+
+// The float3 helpers the reference's hot path is built from (external/include/cutil_math.h:322-416), on one
+// pair (a, b) and scalar s. out[0..19] = dot(a,b), length(a), cross(a,b).xyz, normalize(a).xyz,
+// reflect(a,b).xyz, (a*s).xyz, (a/s).xyz, (a+b).x, (a-b).x, (a*b).x
+extern "C" void ref_vec3_ops(const float* pa, const float* pb, float s, float* out) {
+	const float3 a = make_float3(pa[0], pa[1], pa[2]), b = make_float3(pb[0], pb[1], pb[2]);
+	const float3 c = cross(a, b), n = normalize(a), r = reflect(a, b), m = a * s, q = a / s, ad = a + b, sb = a - b, ml = a * b;
+	out[0] = dot(a, b); out[1] = length(a);
+	out[2] = c.x; out[3] = c.y; out[4] = c.z;
+	out[5] = n.x; out[6] = n.y; out[7] = n.z;
+	out[8] = r.x; out[9] = r.y; out[10] = r.z;
+	out[11] = m.x; out[12] = m.y; out[13] = m.z;
+	out[14] = q.x; out[15] = q.y; out[16] = q.z;
+	out[17] = ad.x; out[18] = sb.x; out[19] = ml.x;
+}
+
+extern "C" unsigned int ref_wang_hash(unsigned int seed) { return wang_hash(seed); }

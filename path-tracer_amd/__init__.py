@@ -100,7 +100,7 @@ PTX_SYMBOLS = [
     "ptx_scene_upload", "ptx_scene_free", "ptx_scene_device_bytes", "ptx_render_init", "ptx_render_set_camera",
     "ptx_render_cleanup", "ptx_accum_clear", "ptx_render_samples", "ptx_render_sync", "ptx_accum_device_ptr",
     "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_stats_get", "ptx_stats_reset",
-    "ptx_wavefront_counts", "ptx_ctx_tune", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_trace_rays_queued", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample", "ptx_selftest_rcp",
+    "ptx_wavefront_counts", "ptx_ctx_tune", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_trace_rays_queued", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample", "ptx_selftest_rcp", "ptx_selftest_vec3",
 ]
 
 _lib = None
@@ -155,6 +155,7 @@ def lib():
         L.ptx_generate_rays.argtypes = [vp, C.POINTER(PtxCamera), i32, u64, fp, fp]
         L.ptx_bsdf_eval.argtypes = [vp, i32, C.POINTER(PtxBsdfCase)]
         L.ptx_radiance_sample.argtypes = [vp, vp, i32, u64, fp]
+        L.ptx_selftest_vec3.argtypes = [vp, i32, fp, fp, fp, fp]
         _lib = L
     return _lib
 

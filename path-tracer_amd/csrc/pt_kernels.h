@@ -279,3 +279,22 @@ __global__ __launch_bounds__(PT_BLOCK) void rcp_selftest_kernel(float lo, float 
 		atomicAdd(&out[1], bad);
 	}
 }
+
+// The float3 helpers of pt_math.h on caller-supplied pairs, in the layout of oracle/ref_shim.cpp:ref_vec3_ops
+// (the reference's own cutil_math.h compiled on the host): pins the evaluation order under every hot-path function.
+__global__ __launch_bounds__(PT_BLOCK) void vec3_selftest_kernel(int n, const float* __restrict__ a3, const float* __restrict__ b3,
+                                                                 const float* __restrict__ sc, float* __restrict__ out) {
+	const int i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= n) return;
+	const f3 a = mk3(a3[3 * i], a3[3 * i + 1], a3[3 * i + 2]), b = mk3(b3[3 * i], b3[3 * i + 1], b3[3 * i + 2]);
+	const float s = sc[i];
+	const f3 c = cross3(a, b), nn = normalize3(a), r = reflect3(a, b), m = a * s, q = a * (1.0f / s);
+	float* o = out + 20 * (size_t)i;
+	o[0] = dot3(a, b); o[1] = length3(a);
+	o[2] = c.x; o[3] = c.y; o[4] = c.z;
+	o[5] = nn.x; o[6] = nn.y; o[7] = nn.z;
+	o[8] = r.x; o[9] = r.y; o[10] = r.z;
+	o[11] = m.x; o[12] = m.y; o[13] = m.z;
+	o[14] = q.x; o[15] = q.y; o[16] = q.z;
+	o[17] = (a + b).x; o[18] = (a - b).x; o[19] = (a * b).x;
+}

@@ -1063,6 +1063,26 @@ extern "C" int ptx_selftest_rcp(PtxCtx* ctx, float lo, float hi, uint64_t* check
 	return PTX_OK;
 }
 
+extern "C" int ptx_selftest_vec3(PtxCtx* ctx, int n, const float* a_host, const float* b_host, const float* s_host, float* out_host) {
+	if (!ctx || n < 0 || (n > 0 && (!a_host || !b_host || !s_host || !out_host))) return fail(PTX_E_INVALID, "ptx_selftest_vec3: bad arguments");
+	if (n == 0) return PTX_OK;
+	HIP_TRY(hipSetDevice(ctx->device));
+	DevBuf da, db, ds, dout;
+	HIP_TRY(hipMalloc(&da.p, (size_t)n * 3 * sizeof(float)));
+	HIP_TRY(hipMalloc(&db.p, (size_t)n * 3 * sizeof(float)));
+	HIP_TRY(hipMalloc(&ds.p, (size_t)n * sizeof(float)));
+	HIP_TRY(hipMalloc(&dout.p, (size_t)n * 20 * sizeof(float)));
+	HIP_TRY(hipMemcpyAsync(da.p, a_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(db.p, b_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(hipMemcpyAsync(ds.p, s_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(vec3_selftest_kernel, dim3((unsigned)((n + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream, n,
+	                   (const float*)da.p, (const float*)db.p, (const float*)ds.p, (float*)dout.p);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipMemcpyAsync(out_host, dout.p, (size_t)n * 20 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));
+	return PTX_OK;
+}
+
 extern "C" int ptx_radiance_sample(PtxCtx* ctx, const PtxScene* scene, int sample, uint64_t seed, float* rgb_host) {
 	int rc = check_scene(ctx, scene, "ptx_radiance_sample");
 	if (rc != PTX_OK) return rc;

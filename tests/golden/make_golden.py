@@ -81,6 +81,15 @@ def make_ref_pins():
         f3 = (C.c_float * 3)(); f = C.c_float(); m = C.c_int()
         assert R.ref_resolve(('{"k": %s}' % text).encode(), b"k", f3, C.byref(f), C.byref(m)) == 0
         out["resolve"].append({"json": text, "float3_bits": [bits(x) for x in f3], "float_bits": bits(f.value), "mat_type": m.value})
+    # the float3 helpers of external/include/cutil_math.h and wang_hash of src/cutility.cuh, run by the reference's
+    # own headers: inputs and outputs (bit patterns) go to ref_vec3.npz
+    a, b, s = orc.vec3_cases()
+    bits3 = orc.vec3_ops(R.ref_vec3_ops, a, b, s)
+    seeds = np.concatenate([np.arange(0, 64), np.array([12345, 0x7fffffff, 0x80000000, 0xffffffff]),
+                            np.random.default_rng(7).integers(0, 2 ** 32, 200)]).astype(np.uint32)
+    hashes = np.array([R.ref_wang_hash(int(x)) for x in seeds], np.uint32)
+    np.savez_compressed(os.path.join(HERE, "ref_vec3.npz"), a=a, b=b, s=s, out_bits=bits3, wang_in=seeds, wang_out=hashes)
+    out["vec3"] = {"file": "ref_vec3.npz", "cases": int(len(a)), "sha1_of_outputs": hashlib.sha1(bits3.tobytes()).hexdigest()}
     with open(os.path.join(HERE, "ref_pins.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print("ref_pins.json:", {k: len(v) for k, v in out.items() if not isinstance(v, str)})

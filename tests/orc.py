@@ -36,6 +36,7 @@ def lib():
         L.orc_tonemap.argtypes = [fp, i32, i32, C.c_float, C.POINTER(C.c_ubyte)]
         L.orc_wang_hash.argtypes = [C.c_uint32]
         L.orc_wang_hash.restype = C.c_uint32
+        L.orc_vec3_ops.argtypes = [fp, fp, C.c_float, fp]
         L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.orc_u01.argtypes = [C.c_uint32]
         L.orc_u01.restype = C.c_float
@@ -60,6 +61,10 @@ def ref():
         R.ref_camera_init.argtypes = [C.c_char_p, fp, C.POINTER(C.c_int)]
         R.ref_camera_rotate.argtypes = [C.c_char_p, C.c_float, C.c_float, fp, fp]
         R.ref_resolve.argtypes = [C.c_char_p, C.c_char_p, fp, fp, C.POINTER(C.c_int)]
+        if hasattr(R, "ref_vec3_ops"):
+            R.ref_vec3_ops.argtypes = [fp, fp, C.c_float, fp]
+            R.ref_wang_hash.argtypes = [C.c_uint32]
+            R.ref_wang_hash.restype = C.c_uint32
         _ref = R
     return _ref
 
@@ -112,3 +117,27 @@ def radiance_sample(desc, cam, sample, seed, nthreads=0):
     rgb = np.empty((n, 3), np.float32)
     assert lib().orc_radiance_sample(desc, C.byref(cam), sample, seed, fptr(rgb), nthreads) == 0
     return rgb
+
+
+def vec3_cases():
+    """Deterministic (a, b, s) inputs for the float3-helper pins: random vectors over many magnitudes plus edge
+    cases (zeros, signed zeros, axis vectors, equal / opposite vectors, tiny and huge components)."""
+    rng = np.random.default_rng(2024)
+    n = 400
+    a = (rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-6, 7, size=(n, 1))).astype(np.float32)
+    b = (rng.normal(size=(n, 3)) * 10.0 ** rng.integers(-6, 7, size=(n, 1))).astype(np.float32)
+    s = (rng.normal(size=n) * 10.0 ** rng.integers(-4, 5, size=n)).astype(np.float32)
+    edge = np.array([[0, 0, 0], [0, 0, 1], [1, 0, 0], [0, -1, 0], [-0.0, 0.0, -0.0], [1e-20, 1e-20, 1e-20], [1e18, -1e18, 1e18],
+                     [1, 1, 1], [-1, -1, -1], [3, 4, 0], [1e-38, 0, 0], [0.1, 0.2, 0.3]], np.float32)
+    ea = np.repeat(edge, len(edge), axis=0)
+    eb = np.tile(edge, (len(edge), 1))
+    es = np.resize(np.array([1, -1, 3, 0.5, 1e-3, 7, 1e10], np.float32), len(ea))
+    return np.concatenate([a, ea]), np.concatenate([b, eb]), np.concatenate([s, es])
+
+
+def vec3_ops(fn, a, b, s):
+    """Run a (a, b, s, out20) helper over all cases -> (n, 20) uint32 bit patterns."""
+    out = np.zeros((len(a), 20), np.float32)
+    for i in range(len(a)):
+        fn(fptr(np.ascontiguousarray(a[i])), fptr(np.ascontiguousarray(b[i])), float(s[i]), fptr(out[i]))
+    return out.view(np.uint32)

@@ -102,3 +102,17 @@ def test_json_resolve_pinned(ref, pt, tmp_path):
             assert mat_got.reflect_factor == f.value, text
         if text.startswith('"'):
             assert mat_got.type == m.value, text
+
+
+def test_float3_helpers_and_wang_hash_pinned(ref, orc):
+    """The float3 helpers every hot-path function is built from (dot, cross, length, normalize, reflect, scale,
+    divide-by-scalar, + - *): the oracle's V3 functions against the REFERENCE's own external/include/cutil_math.h,
+    and wang_hash against src/cutility.cuh, both compiled unchanged into oracle/_ref. Bit for bit (a NaN for a NaN)."""
+    a, b, s = orc.vec3_cases()
+    r = orc.vec3_ops(ref.ref_vec3_ops, a, b, s)
+    o = orc.vec3_ops(orc.lib().orc_vec3_ops, a, b, s)
+    same = (r == o) | (np.isnan(r.view(np.float32)) & np.isnan(o.view(np.float32)))
+    assert same.all(), np.nonzero(~same.all(axis=1))[0][:10]
+    assert np.isfinite(r.view(np.float32)).mean() > 0.9
+    for seed in list(range(64)) + [12345, 0x7fffffff, 0x80000000, 0xffffffff]:
+        assert ref.ref_wang_hash(seed) == orc.lib().orc_wang_hash(seed)
