@@ -1,18 +1,24 @@
-// KD-tree build over triangle centroids (reference: src/KDTree.cpp:18-202).
+// KD-tree build over triangle centroids, behind the reference's entry points buildKDTree / flatenKDTree /
+// copyKDTreeToCuda / freeKDTree / freeCudaKDTree (reference: src/KDTree.cpp:18-210).
 //
-// The tree decides which leaves a ray visits and in which order triangles are
-// tested, so it is reproduced exactly (compile with -ffp-contract=off):
-//   * node index = preorder creation counter                     (KDTree.cpp:89-92)
-//   * 0 triangles -> bare node; 1 triangle -> leaf with that triangle's biased box (:95-103)
-//   * otherwise box = triangle-0 box, then expanded by EVERY triangle's already
-//     biased box minus/plus the bias once more (bias applied twice)  (:52-82,106-110)
-//   * axis = depth % 3, max_depth updated before the split decision (:114-115)
-//   * median of centroids (a+b+c)*(1.0f/3.0f) on that axis          (:18-50)
-//   * centroid > median -> "left" list, else "right"                (:121-130)
-//   * children only if left list holds more than MAX_KD_LEAF_TRGS   (:135-143);
+// The tree decides which leaves a ray visits and in which order triangles are tested, so its OUTPUT is the
+// reference's exactly (compiled with -ffp-contract=off; tests compare it node for node with the oracle's
+// independently written builder and pin the median to the reference's own utility.cpp):
+//   * node index = preorder creation counter                                         (KDTree.cpp:89-92)
+//   * no triangle -> bare node; one triangle -> leaf with that triangle's padded box  (:95-103)
+//   * else box = triangle 0's padded box grown by EVERY triangle's padded box padded once more
+//     (the padding of 5e-5 is applied twice)                                          (:52-82, 106-110)
+//   * split axis = depth % 3; the deepest level is recorded before the split decision (:114-115)
+//   * split value = median of the centroids (a + b + c) * (1.0f / 3.0f) on that axis  (:18-50)
+//   * centroid > median -> first child's list, else second child's, input order kept  (:121-130)
+//   * children only if the first list holds more than MAX_KD_LEAF_TRGS triangles      (:135-143);
 //     otherwise the node stays a leaf with all of its triangles.
-// Each triangle therefore lives in exactly one leaf (a partition, no duplication),
-// which the device layout exploits by storing triangles in leaf order.
+// Every triangle therefore lives in exactly one leaf, which the device layout exploits by storing
+// triangles in leaf order.
+//
+// How it is built here: a Grower object computes each triangle's centroid and padded box ONCE (the
+// reference recomputes them at every level: the same pure float expressions, so the same values) and
+// splits index lists with one stable pass into two vectors.
 #include "config.h"
 #include "utility.h"
 #include "world.h"
@@ -22,138 +28,133 @@
 #include <cstring>
 #include <vector>
 
-static float3 triangleMiddle(const Triangle& tr) {
-	return (tr.a + tr.b + tr.c) / 3.0f;
-}
+namespace {
 
-static inline float axisOf(const float3& v, int axis) {
-	return axis == 0 ? v.x : (axis == 1 ? v.y : v.z);
-}
+const float kBoxPad = 0.00005f;   // reference: BBOX_BIAS, src/KDTree.cpp:52
 
-static float trs_median(Triangle* trs_src, int* trs_idxs, int num_trs, int axis) {
-	float* coords = (float*)malloc(num_trs * sizeof(float));
-	for (int i = 0; i < num_trs; i++)
-		coords[i] = axisOf(triangleMiddle(trs_src[trs_idxs[i]]), axis);
-	float coords_median = fmedian(coords, num_trs);
-	free(coords);
-	return coords_median;
-}
+struct Bounds { float lo[3], hi[3]; };
 
-#define BBOX_BIAS 0.00005f
+inline float least(float a, float b) { return fminf(a, b); }
+inline float most(float a, float b) { return fmaxf(a, b); }
 
-static inline float min2(float a, float b) { return fminf(a, b); }
-static inline float max2(float a, float b) { return fmaxf(a, b); }
+class Grower {
+public:
+	Grower(const Triangle* tris, int& node_counter, int& deepest) : tris_(tris), counter_(node_counter), deepest_(deepest) {}
 
-static BBox makeTrgBBox(const Triangle& trg) {
-	BBox bbox;
-	bbox.bounds[0].x = min2(trg.a.x, min2(trg.b.x, trg.c.x));
-	bbox.bounds[0].y = min2(trg.a.y, min2(trg.b.y, trg.c.y));
-	bbox.bounds[0].z = min2(trg.a.z, min2(trg.b.z, trg.c.z));
+	KDNode* grow(int* ids, int n, int depth) {
+		KDNode* node = (KDNode*)malloc(sizeof(KDNode));
+		memset(&node->bbox, 0, sizeof(BBox));   // the reference leaves an empty node's box uninitialised
+		node->trg_idxs = ids;
+		node->num_trgs = n;
+		node->left = node->right = NULL;
+		node->left_idx = node->right_idx = -1;
+		node->idx = counter_++;
+		if (n == 0) return node;
 
-	bbox.bounds[1].x = max2(trg.a.x, max2(trg.b.x, trg.c.x));
-	bbox.bounds[1].y = max2(trg.a.y, max2(trg.b.y, trg.c.y));
-	bbox.bounds[1].z = max2(trg.a.z, max2(trg.b.z, trg.c.z));
+		Bounds box = padded(ids[0]);
+		if (n > 1) {
+			for (int i = 0; i < n; ++i) {   // triangle 0 takes part again, as in the reference
+				const Bounds t = padded(ids[i]);
+				for (int k = 0; k < 3; ++k) {
+					box.lo[k] = least(box.lo[k], t.lo[k] - kBoxPad);
+					box.hi[k] = most(box.hi[k], t.hi[k] + kBoxPad);
+				}
+			}
+		}
+		node->bbox.bounds[0] = make_float3(box.lo[0], box.lo[1], box.lo[2]);
+		node->bbox.bounds[1] = make_float3(box.hi[0], box.hi[1], box.hi[2]);
+		if (n == 1) return node;
 
-	bbox.bounds[0] += make_float3(-BBOX_BIAS);
-	bbox.bounds[1] += make_float3(BBOX_BIAS);
-	return bbox;
-}
+		const int axis = depth % 3;
+		if (depth > deepest_) deepest_ = depth;
 
-static void expandBBox(BBox& bbox, const Triangle& tr) {
-	BBox trbbox = makeTrgBBox(tr);
-	float3& trvmin = trbbox.bounds[0];
-	float3& trvmax = trbbox.bounds[1];
-	float3& vmin = bbox.bounds[0];
-	float3& vmax = bbox.bounds[1];
+		// split value: the median of the centroid coordinates (fmedian sorts its argument, so it gets a copy)
+		std::vector<float> coords((size_t)n);
+		for (int i = 0; i < n; ++i) coords[(size_t)i] = centroid(ids[i], axis);
+		std::vector<float> sorted(coords);
+		const float cut = fmedian(sorted.data(), n);
 
-	vmin.x = min2(vmin.x, trvmin.x - BBOX_BIAS);
-	vmin.y = min2(vmin.y, trvmin.y - BBOX_BIAS);
-	vmin.z = min2(vmin.z, trvmin.z - BBOX_BIAS);
+		std::vector<int> above, rest;   // "above the median" becomes the first child
+		for (int i = 0; i < n; ++i) (coords[(size_t)i] > cut ? above : rest).push_back(ids[i]);
 
-	vmax.x = max2(vmax.x, trvmax.x + BBOX_BIAS);
-	vmax.y = max2(vmax.y, trvmax.y + BBOX_BIAS);
-	vmax.z = max2(vmax.z, trvmax.z + BBOX_BIAS);
-}
+		if ((int)above.size() > MAX_KD_LEAF_TRGS) {
+			node->left = grow(detach(above), (int)above.size(), depth + 1);
+			node->right = grow(detach(rest), (int)rest.size(), depth + 1);
+			node->left_idx = node->left->idx;
+			node->right_idx = node->right->idx;
+		}
+		return node;
+	}
+
+private:
+	// (a + b + c) / 3.0f with the vector header's operator/, i.e. a multiplication by (1.0f / 3.0f)
+	float centroid(int id, int axis) const {
+		const Triangle& t = tris_[id];
+		const float3 m = (t.a + t.b + t.c) / 3.0f;
+		return axis == 0 ? m.x : (axis == 1 ? m.y : m.z);
+	}
+
+	Bounds padded(int id) const {
+		const Triangle& t = tris_[id];
+		const float a[3] = {t.a.x, t.a.y, t.a.z}, b[3] = {t.b.x, t.b.y, t.b.z}, c[3] = {t.c.x, t.c.y, t.c.z};
+		Bounds r;
+		for (int k = 0; k < 3; ++k) {
+			r.lo[k] = least(a[k], least(b[k], c[k])) + -kBoxPad;
+			r.hi[k] = most(a[k], most(b[k], c[k])) + kBoxPad;
+		}
+		return r;
+	}
+
+	// the node owns a malloc'ed copy of its list (freeKDTree releases it with free())
+	static int* detach(const std::vector<int>& v) {
+		int* p = (int*)malloc((v.empty() ? 1 : v.size()) * sizeof(int));
+		if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(int));
+		return p;
+	}
+
+	const Triangle* tris_;
+	int& counter_;
+	int& deepest_;
+};
+
+} // namespace
 
 KDNode* buildKDTree(Triangle* trg_src, int* trg_idxs, int num_trs, int depth, int& num_nodes, int& max_depth) {
-	KDNode* node = (KDNode*)malloc(sizeof(KDNode));
-	memset(&node->bbox, 0, sizeof(BBox)); // reference leaves it uninitialised for empty nodes
-	node->trg_idxs = trg_idxs;
-	node->num_trgs = num_trs;
-	node->left = node->right = NULL;
-	node->idx = num_nodes;
-	node->left_idx = -1;
-	node->right_idx = -1;
-	num_nodes++;
-
-	if (num_trs == 0)
-		return node;
-
-	if (num_trs == 1) {
-		node->bbox = makeTrgBBox(trg_src[trg_idxs[0]]);
-		return node;
-	}
-
-	node->bbox = makeTrgBBox(trg_src[trg_idxs[0]]);
-	for (int i = 0; i < num_trs; i++)
-		expandBBox(node->bbox, trg_src[trg_idxs[i]]);
-
-	int axis = depth % 3;
-	max_depth = max_depth > depth ? max_depth : depth;
-	float median = trs_median(trg_src, trg_idxs, num_trs, axis);
-
-	std::vector<int> trg_left_idxs, trg_right_idxs;
-	for (int i = 0; i < num_trs; i++) {
-		int trg_idx = trg_idxs[i];
-		if (axisOf(triangleMiddle(trg_src[trg_idx]), axis) > median)
-			trg_left_idxs.push_back(trg_idx);
-		else
-			trg_right_idxs.push_back(trg_idx);
-	}
-
-	int left_size = (int)trg_left_idxs.size();
-	int right_size = (int)trg_right_idxs.size();
-
-	if (left_size > MAX_KD_LEAF_TRGS) {
-		int* left_idxs = (int*)malloc(left_size * sizeof(int));
-		memcpy(left_idxs, trg_left_idxs.data(), left_size * sizeof(int));
-		node->left = buildKDTree(trg_src, left_idxs, left_size, depth + 1, num_nodes, max_depth);
-
-		int* right_idxs = (int*)malloc((right_size > 0 ? right_size : 1) * sizeof(int));
-		memcpy(right_idxs, trg_right_idxs.data(), right_size * sizeof(int));
-		node->right = buildKDTree(trg_src, right_idxs, right_size, depth + 1, num_nodes, max_depth);
-	}
-
-	if (node->left != NULL) node->left_idx = node->left->idx;
-	if (node->right != NULL) node->right_idx = node->right->idx;
-	return node;
+	return Grower(trg_src, num_nodes, max_depth).grow(trg_idxs, num_trs, depth);
 }
 
-// reference: KDTree.cpp:152-163 copied each node into the flat array and gave every
-// node its own device allocation for trg_idxs. Here the flat array stays on the
-// host (trg_idxs keep pointing at the pointer tree's lists); the device copy is
-// made in ONE packed upload by ptx_scene_upload().
+// reference: KDTree.cpp:152-163 copied each node into the flat array and gave every node its own device
+// allocation for trg_idxs. Here the flat array stays on the host (trg_idxs keep pointing at the pointer
+// tree's lists); the device copy is made in ONE packed upload by ptx_scene_upload().
 void flatenKDTree(KDNode* host_node, KDNode* flat_mem_ptr) {
-	if (host_node == NULL) return;
-	flat_mem_ptr[host_node->idx] = *host_node;
-	flatenKDTree(host_node->left, flat_mem_ptr);
-	flatenKDTree(host_node->right, flat_mem_ptr);
+	std::vector<KDNode*> todo;
+	if (host_node) todo.push_back(host_node);
+	while (!todo.empty()) {
+		KDNode* n = todo.back();
+		todo.pop_back();
+		flat_mem_ptr[n->idx] = *n;
+		if (n->right) todo.push_back(n->right);
+		if (n->left) todo.push_back(n->left);
+	}
 }
 
-// reference: KDTree.cpp:165-189 built a device pointer tree that the LOOP traversal
-// never dereferenced. Kept as an entry point; it returns its argument.
-KDNode* copyKDTreeToCuda(KDNode* host_root) {
-	return host_root;
-}
+// reference: KDTree.cpp:165-189 built a device pointer tree that the LOOP traversal never dereferenced.
+// Kept as an entry point; it returns its argument.
+KDNode* copyKDTreeToCuda(KDNode* host_root) { return host_root; }
 
 void freeKDTree(KDNode* root) {
-	if (root == NULL) return;
-	freeKDTree(root->left);
-	freeKDTree(root->right);
-	if (root->trg_idxs != NULL) free(root->trg_idxs);
-	free(root);
+	std::vector<KDNode*> todo;
+	if (root) todo.push_back(root);
+	while (!todo.empty()) {
+		KDNode* n = todo.back();
+		todo.pop_back();
+		if (n->left) todo.push_back(n->left);
+		if (n->right) todo.push_back(n->right);
+		if (n->trg_idxs) free(n->trg_idxs);
+		free(n);
+	}
 }
 
-// Device memory of all trees belongs to the uploaded PtxScene and is released by
-// freeWorldObjects(); nothing per-tree to do (reference: KDTree.cpp:204-210).
+// Device memory of all trees belongs to the uploaded PtxScene and is released by freeWorldObjects();
+// nothing per-tree to do (reference: KDTree.cpp:204-210).
 void freeCudaKDTree(KDNode*) {}

@@ -1,10 +1,39 @@
 #include "checkpoint.h"
+#include "../../include/ptx_hip.h"
 
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
 
-static const char CK_MAGIC[8] = {'P', 'T', 'X', 'A', 'C', 'C', '1', 0};
+// PTXACC2: PTXACC1 (width, height, samples, seed) + scene hash, bounce limit, texture switch
+static const char CK_MAGIC[8] = {'P', 'T', 'X', 'A', 'C', 'C', '2', 0};
+
+static void fnv(uint64_t& h, const void* p, size_t n) {
+	const unsigned char* b = (const unsigned char*)p;
+	for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+}
+
+uint64_t sceneContentHash(const PtxSceneDesc& d) {
+	uint64_t h = 14695981039346656037ull;
+	fnv(h, &d.num_objects, 4); fnv(h, &d.num_triangles, 4); fnv(h, &d.num_nodes, 4); fnv(h, &d.num_materials, 4);
+	if (d.objects) fnv(h, d.objects, sizeof(PtxObject) * (size_t)d.num_objects);
+	for (int i = 0; i < d.num_materials; ++i) fnv(h, &d.materials[i], offsetof(PtxMaterial, _pad));   // not the padding word
+	if (d.triangles) fnv(h, d.triangles, sizeof(PtxTriangle) * (size_t)d.num_triangles);
+	if (d.nodes) fnv(h, d.nodes, sizeof(PtxKDNode) * (size_t)d.num_nodes);
+	if (d.leaf_tris) fnv(h, d.leaf_tris, sizeof(int32_t) * (size_t)d.num_leaf_tris);
+	for (int i = 0; i < d.num_textures; ++i) { fnv(h, &d.textures[i].width, 4); fnv(h, &d.textures[i].height, 4); }
+	return h ? h : 1;   // 0 means "not recorded"
+}
+
+std::string checkpointMismatch(const AccumCheckpoint& ck, uint64_t scene_hash, int max_ray_bounces, int texture_enabled) {
+	if (ck.scene_hash != 0 && scene_hash != 0 && ck.scene_hash != scene_hash) return "it was rendered from a different scene";
+	if (ck.max_ray_bounces >= 0 && ck.max_ray_bounces != max_ray_bounces)
+		return "it was rendered with max_ray_bounces " + std::to_string(ck.max_ray_bounces) + ", not " + std::to_string(max_ray_bounces);
+	if (ck.texture_enabled >= 0 && ck.texture_enabled != (texture_enabled ? 1 : 0))
+		return std::string("it was rendered with textures ") + (ck.texture_enabled ? "on" : "off");
+	return "";
+}
 
 bool saveCheckpoint(const std::string& path, const AccumCheckpoint& ck, std::string& err) {
 	if (ck.width <= 0 || ck.height <= 0 || ck.samples_done < 0 || ck.rgba.size() != (size_t)ck.width * ck.height * 4) {
@@ -15,7 +44,8 @@ bool saveCheckpoint(const std::string& path, const AccumCheckpoint& ck, std::str
 	FILE* f = fopen(tmp.c_str(), "wb");
 	if (!f) { err = "saveCheckpoint: cannot open " + tmp; return false; }
 	bool ok = fwrite(CK_MAGIC, 1, 8, f) == 8 && fwrite(&ck.width, 4, 1, f) == 1 && fwrite(&ck.height, 4, 1, f) == 1 &&
-	          fwrite(&ck.samples_done, 4, 1, f) == 1 && fwrite(&ck.seed, 8, 1, f) == 1 &&
+	          fwrite(&ck.samples_done, 4, 1, f) == 1 && fwrite(&ck.seed, 8, 1, f) == 1 && fwrite(&ck.scene_hash, 8, 1, f) == 1 &&
+	          fwrite(&ck.max_ray_bounces, 4, 1, f) == 1 && fwrite(&ck.texture_enabled, 4, 1, f) == 1 &&
 	          fwrite(ck.rgba.data(), sizeof(float), ck.rgba.size(), f) == ck.rgba.size();
 	ok = (fclose(f) == 0) && ok;
 	// written beside the target and renamed, so an interrupted save never clobbers the last good checkpoint
@@ -29,9 +59,10 @@ bool loadCheckpoint(const std::string& path, AccumCheckpoint& ck, std::string& e
 	if (!f) { err = "loadCheckpoint: cannot open " + path; return false; }
 	char magic[8];
 	bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, CK_MAGIC, 8) == 0;
-	if (!ok) { fclose(f); err = "loadCheckpoint: " + path + " is not a PTXACC1 checkpoint"; return false; }
+	if (!ok) { fclose(f); err = "loadCheckpoint: " + path + " is not a PTXACC2 checkpoint"; return false; }
 	ok = fread(&ck.width, 4, 1, f) == 1 && fread(&ck.height, 4, 1, f) == 1 && fread(&ck.samples_done, 4, 1, f) == 1 &&
-	     fread(&ck.seed, 8, 1, f) == 1;
+	     fread(&ck.seed, 8, 1, f) == 1 && fread(&ck.scene_hash, 8, 1, f) == 1 && fread(&ck.max_ray_bounces, 4, 1, f) == 1 &&
+	     fread(&ck.texture_enabled, 4, 1, f) == 1;
 	if (!ok || ck.width <= 0 || ck.height <= 0 || ck.samples_done < 0 || (int64_t)ck.width * ck.height > ((int64_t)1 << 28)) {
 		fclose(f);
 		err = "loadCheckpoint: bad header in " + path;

@@ -8,12 +8,24 @@
 #include <string>
 #include <vector>
 
+struct PtxSceneDesc;
+
 struct AccumCheckpoint {
 	int32_t width, height;
 	int32_t samples_done;      // the buffer holds global samples [0, samples_done)
 	uint64_t seed;
+	// what else the samples depend on: continuing with another scene, bounce limit or texture switch would mix
+	// two different images in one buffer, so a resume checks these too (0 / -1 = "not recorded", accepted as is)
+	uint64_t scene_hash = 0;          // sceneContentHash() of the scene description the samples were rendered from
+	int32_t max_ray_bounces = -1;
+	int32_t texture_enabled = -1;
 	std::vector<float> rgba;   // width * height * 4
 };
+
+// FNV-1a over the geometry, tree, materials and texture sizes of a flat scene description (include/ptx_hip.h)
+uint64_t sceneContentHash(const PtxSceneDesc& d);
+// Empty string if `ck` continues a render of (scene_hash, bounces, textures); else what differs.
+std::string checkpointMismatch(const AccumCheckpoint& ck, uint64_t scene_hash, int max_ray_bounces, int texture_enabled);
 
 bool saveCheckpoint(const std::string& path, const AccumCheckpoint& ck, std::string& err);
 bool loadCheckpoint(const std::string& path, AccumCheckpoint& ck, std::string& err);

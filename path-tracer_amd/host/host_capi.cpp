@@ -4,6 +4,7 @@
 #include "hostscene.h"
 #include "image_io.h"
 #include "kernel.h"
+#include "pathtracing.h"
 #include "scenestate.h"
 #include "utility.h"
 #include "world_load.h"
@@ -189,6 +190,8 @@ extern "C" int pth_kd_build(const float* abc, int n, PtxKDNode** nodes_out, int3
 }
 
 extern "C" void pth_free(void* p) { free(p); }
+extern "C" unsigned int pth_wang_hash(unsigned int x) { return wang_hash(x); }
+extern "C" unsigned int pth_wang_unhash(unsigned int h) { return wang_unhash(h); }
 extern "C" float pth_fmedian(float* arr, int n) { return fmedian(arr, n); }
 
 extern "C" int pth_load_image_float(const char* path, int* w, int* h, int* channels, float** pixels_out) {
@@ -237,6 +240,9 @@ extern "C" int pth_checkpoint_save(const char* path, int samples_done) {
 	ck.height = sc.camera.projection.height;
 	ck.samples_done = samples_done;
 	ck.seed = kernelSeed();
+	ck.scene_hash = sceneContentHash(hostSceneFlat().desc);
+	ck.max_ray_bounces = sc.camera.max_ray_bounces;
+	ck.texture_enabled = sc.camera.texture_enabled ? 1 : 0;
 	ck.rgba.resize((size_t)ck.width * ck.height * 4);
 	int rc = ptx_accum_download(ctx, ck.rgba.data());
 	if (rc != PTX_OK) { g_err = ptx_last_error(); return rc; }
@@ -258,6 +264,8 @@ extern "C" int pth_checkpoint_load(const char* path, int* samples_done) {
 		return PTX_E_INVALID;
 	}
 	if (ck.seed != kernelSeed()) { g_err = "pth_checkpoint_load: checkpoint was rendered with another seed"; return PTX_E_INVALID; }
+	const std::string why = checkpointMismatch(ck, sceneContentHash(hostSceneFlat().desc), sc.camera.max_ray_bounces, sc.camera.texture_enabled ? 1 : 0);
+	if (!why.empty()) { g_err = "pth_checkpoint_load: checkpoint does not continue this render: " + why; return PTX_E_INVALID; }
 	int rc = ptx_accum_upload(ctx, ck.rgba.data());
 	if (rc != PTX_OK) { g_err = ptx_last_error(); return rc; }
 	*samples_done = ck.samples_done;

@@ -29,6 +29,8 @@ PtxScene* pth_scene_device(void);
 int pth_camera_get(PtxCamera* out);
 int pth_camera_control(const char* what, float value); /* "h_ang","v_ang","pos_x","pos_y","pos_z","reset","bounces","aa_jitter","gamma","preview","aabb","textures" */
 int pth_log_lines(char* buf, int buf_len);
+unsigned int pth_wang_hash(unsigned int x);
+unsigned int pth_wang_unhash(unsigned int h);
 int pth_texture_failures(char* buf, int buf_len);
 
 /* kernel.h */

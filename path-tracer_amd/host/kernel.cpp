@@ -1,5 +1,6 @@
 // Render boundary over the C ABI (reference: src/kernel.cu:22-103).
 #include "kernel.h"
+#include "pathtracing.h"
 
 #include <cstdio>
 #include <cstring>
@@ -51,8 +52,10 @@ void fillPtxCamera(const Camera& cam, PtxCamera* out) {
 	out->texture_enabled = cam.texture_enabled ? 1 : 0;
 }
 
-// reference: src/kernel.cu:22-28 kernelInit (+ initPathTracing, src/pathtracing.cu:44-62)
-void kernelInit(const Scene& scene) {
+// reference: src/pathtracing.cu:44-62 initPathTracing: the render-side buffers. The reference allocates the ray
+// and pixel-midpoint buffers here and generates the primary rays; primaries are regenerated in-kernel, so what is
+// left is the float accumulation buffer behind the C ABI (ptx_render_init allocates and clears it).
+void initPathTracing(const Scene& scene) {
 	PtxCtx* ctx = kernelContext();
 	if (!ctx) { g_last_status = PTX_E_NO_DEVICE; return; }
 	PtxCamera pc;
@@ -63,11 +66,35 @@ void kernelInit(const Scene& scene) {
 	if (!g_render_ready) fprintf(stderr, "\n>  HIP RESULT FAIL: %s\n\n", ptx_last_error());
 }
 
-// reference: src/kernel.cu:30-35
-void kernelCleanUp() {
+// reference: src/pathtracing.cu:64-70 cleanUpPathTracing
+void cleanUpPathTracing() {
 	if (g_ctx) ptx_render_cleanup(g_ctx);
 	device_accum_image = NULL;
 	g_render_ready = false;
+}
+
+// reference: src/kernel.cu:22-28 kernelInit: accumulation buffer + initPathTracing (one call here: the buffer
+// lives behind the same C ABI call)
+void kernelInit(const Scene& scene) { initPathTracing(scene); }
+
+// reference: src/kernel.cu:30-35
+void kernelCleanUp() { cleanUpPathTracing(); }
+
+unsigned int wang_unhash(unsigned int h) {
+	h ^= (h >> 15) ^ (h >> 30);                 // undo seed ^= seed >> 15
+	h *= 0xfb699ca5u;                           // inverse of 0x27d4eb2d modulo 2^32
+	h ^= (h >> 4) ^ (h >> 8) ^ (h >> 12) ^ (h >> 16) ^ (h >> 20) ^ (h >> 24) ^ (h >> 28);   // undo seed ^= seed >> 4
+	h *= 0x38e38e39u;                           // inverse of 9 modulo 2^32
+	const unsigned int hi = h >> 16;            // (x ^ 61) ^ (x >> 16): the top half of x is untouched (61 < 2^16)
+	return (hi << 16) | ((h & 0xffffu) ^ 61u ^ hi);
+}
+
+// reference: src/pathtracing.cu:156-182 runPathTracing
+void runPathTracing(Scene& scene, int iterHash, int jitterHash) {
+	(void)jitterHash;
+	const unsigned int iter = wang_unhash((unsigned int)iterHash);
+	if (iter < 1u || iter > 0x7fffffffu) { g_last_status = PTX_E_INVALID; return; }
+	renderSamples(scene, (int)iter - 1, 1, false);
 }
 
 int renderSamples(Scene& scene, int first_sample, int num_samples, bool collect_stats) {
@@ -94,8 +121,12 @@ int kernelMain(uchar4* pbo, Scene& scene, int iter) {
 		int rc = ptx_accum_clear(ctx); // :69-72
 		if (rc != PTX_OK) return g_last_status = rc;
 	}
-	int rc = renderSamples(scene, iter - 1, 1, false);
-	if (rc != PTX_OK) return rc;
+	// :74-80 the reference's per-iteration hashes; runPathTracing recovers the iteration from them
+	const int iterHash = (int)wang_hash((unsigned int)iter);
+	const int jitterHash = (int)wang_hash(wang_hash((unsigned int)iter));
+	runPathTracing(scene, iterHash, jitterHash);
+	if (g_last_status != PTX_OK) return g_last_status;
+	int rc;
 	// :83-88 writeImageToPBO
 	rc = ptx_tonemap(ctx, iter, scene.camera.projection.gamma_corr, (unsigned char*)pbo);
 	return g_last_status = rc;

@@ -12,6 +12,7 @@
 #include "world_load.h"
 #include "image_io.h"
 #include "checkpoint.h"
+#include "hostscene.h"
 
 #include <chrono>
 #include <cstdio>
@@ -98,6 +99,9 @@ int main(int argc, char** argv) {
 	auto save_checkpoint = [&](int done) {
 		AccumCheckpoint ck;
 		ck.width = W; ck.height = H; ck.samples_done = done; ck.seed = seed;
+		ck.scene_hash = sceneContentHash(hostSceneFlat().desc);
+		ck.max_ray_bounces = scene.camera.max_ray_bounces;
+		ck.texture_enabled = scene.camera.texture_enabled ? 1 : 0;
 		ck.rgba.resize((size_t)W * H * 4);
 		if (ptx_accum_download(ctx, ck.rgba.data()) != PTX_OK || !saveCheckpoint(ck_path, ck, err))
 			fprintf(stderr, "checkpoint failed: %s %s\n", err.c_str(), ptx_last_error());
@@ -110,6 +114,16 @@ int main(int argc, char** argv) {
 		if (ck.width != W || ck.height != H || ck.seed != seed) {
 			fprintf(stderr, "checkpoint %s is %dx%d seed %llu, this run is %dx%d seed %llu\n", resume_path.c_str(), ck.width, ck.height,
 			        (unsigned long long)ck.seed, W, H, seed);
+			return 1;
+		}
+		const std::string why = checkpointMismatch(ck, sceneContentHash(hostSceneFlat().desc), scene.camera.max_ray_bounces,
+		                                           scene.camera.texture_enabled ? 1 : 0);
+		if (!why.empty()) { fprintf(stderr, "checkpoint %s does not continue this render: %s\n", resume_path.c_str(), why.c_str()); return 1; }
+		if (ck.samples_done > spp) {
+			// the buffer already holds more samples than asked for: dividing it by --spp would brighten the image and
+			// saving it as "spp samples" would make the next resume count samples twice
+			fprintf(stderr, "checkpoint %s holds %d samples, more than --spp %d: nothing to render (ask for at least %d)\n",
+			        resume_path.c_str(), ck.samples_done, spp, ck.samples_done);
 			return 1;
 		}
 		if (ptx_accum_upload(ctx, ck.rgba.data()) != PTX_OK) { fprintf(stderr, "%s\n", ptx_last_error()); return 1; }

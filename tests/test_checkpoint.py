@@ -70,3 +70,29 @@ def test_resume_is_bit_identical_to_an_uninterrupted_run(pt, ctx, tmp_path):
     assert H.pth_kernel_init() == 0
     assert H.pth_checkpoint_load(path, C.byref(done)) != 0 and b"resolution" in H.pth_last_error()
     H.pth_set_seed(0)
+
+
+@pytest.mark.gpu
+def test_checkpoint_of_another_scene_bounce_limit_or_texture_switch_is_refused(pt, ctx, tmp_path):
+    """The header records what the samples depend on besides seed and resolution (scene content hash, bounce limit,
+    texture switch): a resume that would mix two different images in one buffer is refused with a message."""
+    import gpuops
+    H = pt.host()
+    H.pth_set_seed(5)
+    desc, cam = pt.load_scene("teapot", width=64, height=48)
+    assert H.pth_kernel_init() == 0
+    gpuops.render(ctx, H.pth_scene_device(), cam, 0, 2, 5)
+    path = str(tmp_path / "a.ptxacc").encode()
+    assert H.pth_checkpoint_save(path, 2) == 0, H.pth_last_error()
+    done = C.c_int32()
+    assert H.pth_checkpoint_load(path, C.byref(done)) == 0 and done.value == 2
+    pt.load_scene("teapot", width=64, height=48, bounces=3)
+    assert H.pth_kernel_init() == 0
+    assert H.pth_checkpoint_load(path, C.byref(done)) != 0 and b"max_ray_bounces" in H.pth_last_error()
+    pt.load_scene("teapot", width=64, height=48, textures=1)
+    assert H.pth_kernel_init() == 0
+    assert H.pth_checkpoint_load(path, C.byref(done)) != 0 and b"textures" in H.pth_last_error()
+    pt.load_scene("geoms", width=64, height=48)
+    assert H.pth_kernel_init() == 0
+    assert H.pth_checkpoint_load(path, C.byref(done)) != 0 and b"different scene" in H.pth_last_error()
+    H.pth_set_seed(0)

@@ -440,3 +440,30 @@ def test_shading_divergence_counters_are_consistent(pt, ctx):
     assert d["sh_type1"] > 0 and d["sh_type2"] > 0 and d["sh_type3"] > 0 and d["sh_type0"] > 0   # geoms has all four
     assert 0 < d["sh_waves"] <= d["sh_lanes"] and d["sh_branches"] <= 3 * d["sh_waves"]
     assert d["sh_branches"] >= d["sh_waves"] * 0.5
+
+
+def test_4k_path_cap_splits_passes_without_changing_the_image(pt, ctx):
+    """BASELINE config C5 (scene_sky_map at 3840x2160): 128 samples of 8.29 M padded pixels exceed the 2^28-path cap of
+    one wavefront pass, so ptx_render_samples cuts the request into 32-sample passes. Size-independent properties
+    only (the oracle would need minutes here): a request that spans several passes equals the same samples rendered
+    in two calls and with another pass size, bit for bit, and every (pixel, sample) path is counted once."""
+    desc, cam = pt.load_scene("sky_map", width=3840, height=2160, textures=1)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    npix = 3840 * 2160
+    whole, st = gpuops.render(ctx, scene, cam, 0, 40, 3)          # passes of 32 + 8 samples
+    assert st.paths == 40 * npix and st.paths <= st.rays <= 5 * st.paths
+    assert np.isfinite(whole).all() and whole[:, :3].max() > 0 and (whole[:, 3] == 0).all()
+    two, st2 = gpuops.render(ctx, scene, cam, 0, 40, 3, batch=33)  # calls of 33 + 7: passes of 32 + 1, then 7
+    assert np.array_equal(whole.view(np.uint32), two.view(np.uint32)) and st2.rays == st.rays
+    try:
+        _tune(pt, ctx, b"wf_batch", 16)
+        small, st3 = gpuops.render(ctx, scene, cam, 0, 40, 3)      # passes of 16 + 16 + 8
+        assert np.array_equal(whole.view(np.uint32), small.view(np.uint32)) and st3.rays == st.rays
+    finally:
+        _tune(pt, ctx, b"wf_batch", -1)
+    # the split across two ranks of this configuration: partial buffers sum to the whole up to float summation order
+    a, _ = gpuops.render(ctx, scene, cam, 0, 20, 3)
+    b, _ = gpuops.render(ctx, scene, cam, 20, 20, 3)
+    assert (np.abs(a + b - whole) / np.maximum(np.abs(whole), 1e-3)).max() < 1e-5
+    pt.check(pt.lib().ptx_render_cleanup(ctx))                     # give the 40 GB of path state back
