@@ -107,6 +107,13 @@ static int env_int(const char* name, int dflt) {
 }
 
 #define PT_GRP_PAD_PPM_DEFAULT 100
+// queue chunk a wave claims at a time and descent threshold of the default traversal kernel (pt_wavefront.h)
+#ifndef WF_CHUNK
+#define WF_CHUNK 128
+#endif
+#ifndef WF_ATHRESH
+#define WF_ATHRESH 28
+#endif
 
 struct Tuning {
 	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm;
@@ -677,7 +684,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
 		else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
 		else if (ctx->trav_variant == 10 || ctx->trav_variant == 11) COOP(PT_F_STATS, 4, 128, 28, 5);
-		else COOP(PT_F_STATS, 4, 128, 28, 6);   // the counting twin of the default kernel
+		else COOP(PT_F_STATS, 4, WF_CHUNK, WF_ATHRESH, 6);   // the counting twin of the default kernel
 	} else switch (ctx->trav_variant) {
 		case 1: TRAV(0, 1, 3, 0); break;
 		case 2: TRAV(0, 1, 3, 64); break;
@@ -692,7 +699,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		case 11: if (grp_fits) COOP(0, 4, 128, 28, 5); else COOP(0, 4, 64, 32, 3); break;
 		case 12: if (uni_fits) UNI(0, 5, 128, 16); else COOP(0, 4, 64, 32, 3); break;
 		default:
-			if (grp_fits) COOP(0, 4, 128, 28, 6);
+			if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 6);
 			else if (stage_fits) COOP(0, 5, 64, 32, 4);
 			else COOP(0, 4, 64, 32, 3);
 			break;
