@@ -59,9 +59,9 @@ def logical_bytes_and_flops(st):
 def executed_bytes_and_flops(st):
     """What the traversal kernel itself requests and computes (counting twin of the default kernel, PtxStats.x_*):
     a 64-B node record and one packed two-box test per descending lane and iteration; the four group boxes of a
-    leaf (128 B, four slab tests) per leaf visit; 320 B and eight triangle tests per work unit; per traversal the
-    queue entry, ray state in and the closest-hit record out (64 B)."""
-    b = 64 * st["x_item_lanes"] + 128 * st["x_half_lanes"] + 320 * st["x_units"] + 64 * st["trav_rays"]
+    leaf (48 B in their quantised form, four slab tests) per leaf visit; 320 B and eight triangle tests per work
+    unit; per traversal the queue entry, ray state in and the closest-hit record out (64 B)."""
+    b = 64 * st["x_item_lanes"] + 48 * st["x_half_lanes"] + 320 * st["x_units"] + 64 * st["trav_rays"]
     f = 22 * (2 * st["x_item_lanes"] + 4 * st["x_half_lanes"]) + 48 * 8 * st["x_units"]
     return b, f
 
@@ -221,7 +221,7 @@ def main():
     launch_ms = float(trav_ms.value if trav_dominant else seg_ms.value) / n_launch   # HIP event pairs around every launch
     launch_s = max(launch_ms * 1e-3, 1e-12)
     tr = max(1, cd["trav_rays"])
-    kernel = "wf_traverse_coop_kernel<0,4,128,28,6>" if trav_dominant else "wf_segment_kernel<0>"
+    kernel = "wf_traverse_coop_kernel<0,4,128,28,9>" if trav_dominant else "wf_segment_kernel<0>"
     xb, xf = executed_bytes_and_flops(cd)
     lb, lf = logical_bytes_and_flops(cd)
     x_tflops = xf / n_launch / launch_s / 1e12 if trav_dominant else 0.0

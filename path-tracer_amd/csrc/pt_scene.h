@@ -52,6 +52,13 @@
 //              `nodes` (index half_base + 2 * block + h = groups 2h, 2h + 1 of that 32-triangle block), in the
 //              layout of an inner node's two child boxes, so that the unified traversal kernel tests a
 //              leaf's groups with the same fetch and the same packed box test as an inner step.
+//   grp_qbox   the four group boxes of a 32-triangle block a third time, in 48 B (leaf mode 9): the union U of the
+//              four boxes as origin and step = extent / 255 per axis (6 floats), then per box six BYTES
+//              (lo.xyz rounded down, hi.xyz rounded up, in steps from U's origin): words
+//                f0 = (U.lo.x, U.lo.y, U.lo.z, step.x)  f1 = (step.y, step.z, bytes 0-3, bytes 4-7)  f2 = bytes 8-23
+//              box g's bytes are 6g .. 6g+5; an unused group slot is (255, 255, 255, 0, 0, 0): never touched.
+//              The decoded box contains the fp32 one (outward rounding, at most 1/255 of the block's extent per
+//              side), so the filter stays conservative; three 16-B loads per leaf instead of eight.
 //   tri_shade  4 x float4 per triangle (64 B), same order, touched once per mesh hit:
 //                s0 = (na.xyz, ta.x) s1 = (nb.xyz, ta.y) s2 = (nc.xyz, tb.x)
 //                s3 = (tb.y, tc.x, tc.y, int material_global_idx)
@@ -94,6 +101,7 @@ struct DevScene {
 	const float4* tri_pair;
 	const float4* tri_grp;
 	const float4* grp_box;
+	const float4* grp_qbox; // 3 float4 (48 B) per 32-triangle block: the block's four group boxes quantised to 8 bits (below)
 	const float4* tri_shade;
 	const float4* materials;
 	const DevTexture* textures;

@@ -720,7 +720,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			const int n_desc = (int)__popcll(__ballot(state == DESCEND));
 			if (n_desc == 0 || (iter > 0 && n_desc <= ATHRESH)) break;
 			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; x_iters++; } if (state == DESCEND) x_item++; }
-			if (FLAT == 6) {
+			if (FLAT == 6 || FLAT == 9) {
 				// Leaf mode 6 = mode 5 + node records fetched by the QUAD: in pass k the four lanes of a quad
 				// read the four 16-B parts of the record lane 4q + k wants (one 64-B line: one tag lookup in
 				// the L1 instead of four, the vector-memory path being this kernel's limit) straight into LDS
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				if (FLAGS & PT_F_STATS) { act++;  }
 				const int curr = ts.curr;
 				float4 q0, q1, q2, q3;
-				if (FLAT == 6) {
+				if (FLAT == 6 || FLAT == 9) {
 					const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) +
 					                                                    (tid >> 6) * WF_GRP_WAVE_BYTES + (lane & 3) * 1024 + (lane >> 2) * 64);
 					q3 = rec[3]; q0 = rec[0]; q1 = rec[1]; q2 = rec[2];
@@ -846,6 +846,39 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			// the four boxes are one 128-B line and are fetched together, so the pass costs one memory
 			// round trip (a leaf of up to 32 triangles has no more groups) ----
 			uint32_t tb = 0;
+			if (FLAT == 9) {
+				// Leaf mode 9: the four group boxes of the run's first block from their 48-B quantised form (pt_scene.h,
+				// grp_qbox): three 16-B loads instead of eight - this kernel pays per vector-memory instruction
+				// (DESIGN.md 3.2). The decoding is folded into the slab test: (U.lo + q * step - o) * inv =
+				// (U.lo - o) * inv + q * (step * inv); the decoded boxes contain the fp32 ones, so a group is skipped
+				// only if the ray misses a box that holds all its triangles with the usual padding.
+				if (isleaf) {
+					keys[lane] = ~0ull;
+					if (ngroups > 0) {
+						const float4* qp = sc.grp_qbox + 3 * (size_t)leaf_block;
+						const float4 f0 = qp[0], f1 = qp[1], f2 = qp[2];
+						const float ax = (f0.x - ray.o.x) * ray.inv.x, ay = (f0.y - ray.o.y) * ray.inv.y, az = (f0.z - ray.o.z) * ray.inv.z;
+						const float sx = f0.w * ray.inv.x, sy = f1.x * ray.inv.y, sz = f1.y * ray.inv.z;
+						const uint32_t w0 = __float_as_uint(f1.z), w1 = __float_as_uint(f1.w), w2 = __float_as_uint(f2.x),
+						               w3 = __float_as_uint(f2.y), w4 = __float_as_uint(f2.z), w5 = __float_as_uint(f2.w);
+#define WF_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
+						auto hit = [&](float lx, float ly, float lz, float hx, float hy, float hz) {
+							const float tax = __builtin_fmaf(lx, sx, ax), tbx = __builtin_fmaf(hx, sx, ax);
+							const float tay = __builtin_fmaf(ly, sy, ay), tby = __builtin_fmaf(hy, sy, ay);
+							const float taz = __builtin_fmaf(lz, sz, az), tbz = __builtin_fmaf(hz, sz, az);
+							const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)), __builtin_fminf(taz, tbz));
+							const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)), __builtin_fmaxf(taz, tbz));
+							return !(tn > tf) && !(tf < 0.0f);
+						};
+						// box g = bytes 6g .. 6g+5 of the 24
+						tb = (hit(WF_QB(w0, 0), WF_QB(w0, 1), WF_QB(w0, 2), WF_QB(w0, 3), WF_QB(w1, 0), WF_QB(w1, 1)) ? 1u : 0u) |
+						     (ngroups > 1 && hit(WF_QB(w1, 2), WF_QB(w1, 3), WF_QB(w2, 0), WF_QB(w2, 1), WF_QB(w2, 2), WF_QB(w2, 3)) ? 2u : 0u) |
+						     (ngroups > 2 && hit(WF_QB(w3, 0), WF_QB(w3, 1), WF_QB(w3, 2), WF_QB(w3, 3), WF_QB(w4, 0), WF_QB(w4, 1)) ? 4u : 0u) |
+						     (ngroups > 3 && hit(WF_QB(w4, 2), WF_QB(w4, 3), WF_QB(w5, 0), WF_QB(w5, 1), WF_QB(w5, 2), WF_QB(w5, 3)) ? 8u : 0u);
+#undef WF_QB
+					}
+				}
+			} else
 			if (isleaf) {
 				keys[lane] = ~0ull;
 				if (ngroups > 0) {   // the four slots of the run's first block exist whenever the run is not empty

@@ -501,6 +501,56 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 				rec[3] = make_float4(0, 0, 0, 0);
 			}
 	}
+	// Quantised group boxes (pt_scene.h, grp_qbox): per 32-triangle block the union of its (up to) four group boxes
+	// and each box in 8-bit steps of it, rounded outward.
+	std::vector<float4> qboxes(grp_boxes.size() / 8 * 3, make_float4(0, 0, 0, 0));
+	for (size_t b = 0; b < grp_boxes.size() / 8; ++b) {
+		double ulo[3] = {1e300, 1e300, 1e300}, uhi[3] = {-1e300, -1e300, -1e300};
+		bool used[4];
+		for (int g = 0; g < 4; ++g) {
+			const float4 lo = grp_boxes[(4 * b + g) * 2], hi = grp_boxes[(4 * b + g) * 2 + 1];
+			used[g] = lo.x <= hi.x;   // unused slots hold (+inf, -inf)
+			if (!used[g]) continue;
+			const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+			for (int k = 0; k < 3; ++k) { if (l[k] < ulo[k]) ulo[k] = l[k]; if (h[k] > uhi[k]) uhi[k] = h[k]; }
+		}
+		float org[3] = {0, 0, 0}, step[3] = {0, 0, 0};
+		unsigned char q[24];
+		for (int g = 0; g < 4; ++g) { q[6 * g] = q[6 * g + 1] = q[6 * g + 2] = 255; q[6 * g + 3] = q[6 * g + 4] = q[6 * g + 5] = 0; }
+		if (used[0] || used[1] || used[2] || used[3]) {
+			for (int k = 0; k < 3; ++k) {
+				org[k] = (float)ulo[k];
+				if ((double)org[k] > ulo[k]) org[k] = nextafterf(org[k], -INFINITY);
+				step[k] = (float)((uhi[k] - (double)org[k]) / 255.0);
+				// the largest code must reach the union's upper face in float arithmetic as the device decodes it
+				while (!((double)org[k] + 255.0 * (double)step[k] >= uhi[k])) step[k] = nextafterf(step[k], INFINITY);
+			}
+			for (int g = 0; g < 4; ++g) {
+				if (!used[g]) continue;
+				const float4 lo = grp_boxes[(4 * b + g) * 2], hi = grp_boxes[(4 * b + g) * 2 + 1];
+				const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+				for (int k = 0; k < 3; ++k) {
+					int ql = 0, qh = 255;
+					if (step[k] > 0.0f) {
+						ql = (int)floor(((double)l[k] - (double)org[k]) / (double)step[k]);
+						qh = (int)ceil(((double)h[k] - (double)org[k]) / (double)step[k]);
+					}
+					ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+					qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+					while (ql > 0 && (double)org[k] + (double)ql * (double)step[k] > (double)l[k]) --ql;
+					while (qh < 255 && (double)org[k] + (double)qh * (double)step[k] < (double)h[k]) ++qh;
+					q[6 * g + k] = (unsigned char)ql;
+					q[6 * g + 3 + k] = (unsigned char)qh;
+				}
+			}
+		}
+		uint32_t w[6];
+		memcpy(w, q, 24);
+		qboxes[3 * b + 0] = make_float4(org[0], org[1], org[2], step[0]);
+		qboxes[3 * b + 1] = make_float4(step[1], step[2], as_float((int32_t)w[0]), as_float((int32_t)w[1]));
+		qboxes[3 * b + 2] = make_float4(as_float((int32_t)w[2]), as_float((int32_t)w[3]), as_float((int32_t)w[4]), as_float((int32_t)w[5]));
+	}
+	if (qboxes.empty()) qboxes.assign(3, make_float4(0, 0, 0, 0));
 	// the traversal kernels address node / leaf-half records with 32-bit byte offsets from the array base
 	if (nodes.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu KD node and leaf-half records; the limit is 2^26", nodes.size() / 4);
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -537,6 +587,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	if (grp_boxes.empty()) grp_boxes.push_back(make_float4(0, 0, 0, 0));
 	UP(grp_tris, tri_grp)
 	UP(grp_boxes, grp_box)
+	UP(qboxes, grp_qbox)
 	UP(shade, tri_shade)
 	UP(mats, materials)
 #undef UP
@@ -658,6 +709,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 #define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : (T) >= 5 ? WF_GRP_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
 	// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
 	// descent threshold, leaf mode>. Leaf modes (pt_wavefront.h):
+	//   9 = mode 6 with the four group boxes of a leaf read from their 48-B quantised form: 3 loads instead of 8  <- default
 	//   6 = mode 5 with the node records fetched by the quad through LDS (one L1 tag lookup per record)
 	//   5 = boxed groups of eight triangles inside the leaves: group boxes per lane, the touched
 	//       groups sixteen per step (needs WF_GRP_BYTES of LDS behind the stacks)
@@ -668,7 +720,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   2 = mode 1 with two steps' loads in flight.
 	// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
 	// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
-	//   0: 3420 (128-sample passes; the other figures are 64-sample passes)   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+	//   0: 3830 (leaf mode 9, 128-sample passes; the other figures are 64-sample passes of round 1)   13: leaf mode 6 (3690)   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
 	//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
 	//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
 	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3090)   11: mode 5 (3150)
@@ -684,7 +736,8 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
 		else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
 		else if (ctx->trav_variant == 10 || ctx->trav_variant == 11) COOP(PT_F_STATS, 4, 128, 28, 5);
-		else COOP(PT_F_STATS, 4, WF_CHUNK, WF_ATHRESH, 6);   // the counting twin of the default kernel
+		else if (ctx->trav_variant == 13) COOP(PT_F_STATS, 4, WF_CHUNK, WF_ATHRESH, 6);
+		else COOP(PT_F_STATS, 4, WF_CHUNK, WF_ATHRESH, 9);   // the counting twin of the default kernel
 	} else switch (ctx->trav_variant) {
 		case 1: TRAV(0, 1, 3, 0); break;
 		case 2: TRAV(0, 1, 3, 64); break;
@@ -697,9 +750,10 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
 		case 10: if (grp_fits) COOP(0, 4, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
 		case 11: if (grp_fits) COOP(0, 4, 128, 28, 5); else COOP(0, 4, 64, 32, 3); break;
+		case 13: if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 6); else COOP(0, 4, 64, 32, 3); break;
 		case 12: if (uni_fits) UNI(0, 5, 128, 16); else COOP(0, 4, 64, 32, 3); break;
 		default:
-			if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 6);
+			if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 9);
 			else if (stage_fits) COOP(0, 5, 64, 32, 4);
 			else COOP(0, 4, 64, 32, 3);
 			break;
