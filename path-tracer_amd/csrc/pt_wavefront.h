@@ -556,7 +556,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc,
 // WF_UNIT_CAP 32-bit work units (owner lane | group << 6: 26 bits of group index, i.e. leaves of up to
 // 2^29 triangles, more than a scene may hold)
 #define WF_UNIT_CAP 320
-#define WF_GRP_WAVE_BYTES 4096   /* leaf phase: 64 * 8 + WF_UNIT_CAP * 4 = 1792 B; descent of mode 6: 64 node records */
+#define WF_GRP_WAVE_BYTES 4096   /* leaf phase: 64 * 8 (+ 64 * 8 in mode 9) + WF_UNIT_CAP * 4 = 2304 B; descent of modes 6, 9: 64 node records */
 #define WF_GRP_BYTES ((PT_BLOCK / 64) * WF_GRP_WAVE_BYTES)
 
 PT_DEV uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
@@ -647,6 +647,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	int state = IDLE;
 	int path = 0, leaf_first = 0, leaf_count = 0, leaf_block = 0;
 	float cur_d = 0.0f;
+	int cur_obj_r = -1;   // leaf mode 9: the path's closest object so far, read at refill
 	Ray ray;
 	TravState ts;
 	ts.curr = -1; ts.sp = 0; ts.tri = -1; ts.tmin = 0.0f; ts.bu = ts.bv = 0.0f; ts.intersects = false;
@@ -657,9 +658,11 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 		if (ts.intersects && ts.tri >= 0) {
 			const f3 p = ray.o + ts.tmin * ray.d;
 			const float d = length3(p - ray.o);
-			const int cur_obj = __float_as_int(wp.s2[path].w);
+			// leaf mode 9 read the path's current hit object at refill (same round trip as the ray) and got u, v of
+			// the winning triangle from the unit step that tested it: its commit issues no load and waits for nothing
+			const int cur_obj = FLAT == 9 ? cur_obj_r : __float_as_int(wp.s2[path].w);
 			if (d < cur_d || (d == cur_d && cur_obj >= 0 && obj_index < cur_obj)) {
-				if (FLAT >= 5) {
+				if (FLAT >= 5 && FLAT != 9) {
 					// mode 5 keeps only (t, triangle) per leaf; u and v are the test's own values, taken
 					// once for the triangle that won (same operations, same bits)
 					float t_, u_, v_;
@@ -703,6 +706,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				const float4 a0 = wp.s0[path], a1 = wp.s1[path];
 				init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
 				cur_d = a0.w;
+				if (FLAT == 9) cur_obj_r = __float_as_int(wp.s2[path].w);
 				trav_begin(ts, ob);
 				state = DESCEND;
 			}
@@ -826,7 +830,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 			// wave works it off and carries on with the remaining groups.
 			unsigned char* area = reinterpret_cast<unsigned char*>(lds_stack + sc.stack_entries * PT_BLOCK) + (tid >> 6) * WF_GRP_WAVE_BYTES;
 			unsigned long long* keys = reinterpret_cast<unsigned long long*>(area);          // one result key per lane
-			uint32_t* units = reinterpret_cast<uint32_t*>(area + 64 * 8);
+			// leaf mode 9: (u, v) of the triangle behind each lane's key, written by the unit step that holds the key
+			float2* uvs = reinterpret_cast<float2*>(area + 64 * 8);
+			uint32_t* units = reinterpret_cast<uint32_t*>(area + 64 * 8 + (FLAT == 9 ? 64 * 8 : 0));
 			const float4* __restrict__ gb = sc.grp_box;
 			const float4* __restrict__ tg = sc.tri_grp;
 			const unsigned long long lt = (1ull << lane) - 1ull;
@@ -950,6 +956,16 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 							const uint32_t k = quad_min_u32(k0 < k1 ? k0 : k1);
 							const uint32_t s0 = __float_as_uint(c4.z), s1 = __float_as_uint(c4.w);   // slots in the unsorted run
 							const uint32_t cand = quad_min_u32(umin3(k0 == k ? s0 : 0xffffffffu, k1 == k ? s1 : 0xffffffffu, 0xffffffffu));
+							if (FLAT == 9) {
+								// the one lane of the quad that holds the quad's best triangle merges it and, if the key it
+								// wrote is the owner's minimum after all lanes' atomics, publishes that triangle's u, v
+								const bool win0 = (k0 == k) & (s0 == cand), win1 = (k1 == k) & (s1 == cand);
+								if (k != 0xffffffffu && (win0 | win1)) {
+									const unsigned long long key = ((unsigned long long)k << 32) | (unsigned long long)cand;
+									atomicMin(&keys[owner], key);
+									if (keys[owner] == key) uvs[owner] = win0 ? make_float2(u.x, v.x) : make_float2(u.y, v.y);
+								}
+							} else
 							if ((lane & 3) == 0 && k != 0xffffffffu)
 								atomicMin(&keys[owner], ((unsigned long long)k << 32) | (unsigned long long)cand);
 						}
@@ -964,7 +980,10 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 				if (key != ~0ull) {
 					ts.intersects = true;
 					const float tt = __uint_as_float((uint32_t)(key >> 32));
-					if (tt < ts.tmin) { ts.tmin = tt; ts.tri = leaf_first + (int)(uint32_t)key; }
+					if (tt < ts.tmin) {
+						ts.tmin = tt; ts.tri = leaf_first + (int)(uint32_t)key;
+						if (FLAT == 9) { const float2 w = uvs[lane]; ts.bu = w.x; ts.bv = w.y; }
+					}
 				}
 			}
 		} else
