@@ -102,6 +102,8 @@ struct DevScene {
 	const float4* tri_grp;
 	const float4* grp_box;
 	const float4* grp_qbox; // 3 float4 (48 B) per 32-triangle block: the block's four group boxes quantised to 8 bits (below)
+	const float4* wide_nodes; // 4 float4 (64 B) per node of the 4-wide tree over the groups (below)
+	const int32_t* wide_root; // per object: its wide root node, -1 if it has none
 	const float4* tri_shade;
 	const float4* materials;
 	const DevTexture* textures;
@@ -109,6 +111,7 @@ struct DevScene {
 	int32_t stack_entries;  // LDS traversal-stack slots per lane (>= deepest tree level, >= 1)
 	int32_t num_tris;       // triangles in tri_geom / per plane of tri_soa
 	int32_t half_base;      // index of the first leaf-half record in `nodes` (behind all node records)
+	int32_t wide_stack;     // most entries a traversal of a wide tree can hold on its stack
 };
 
 struct DevCamera {

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_unified_kernel(DevS
 		if (key != ~0ull) {
 			ts.intersects = true;
 			const float tt = __uint_as_float((uint32_t)(key >> 32));
-			if (tt < ts.tmin) { ts.tmin = tt; ts.tri = leaf_first + (int)(uint32_t)key; }
+			if (tt < ts.tmin) { ts.tmin = tt; ts.tri = (int)(uint32_t)key; }
 		}
 	};
 	// the traversal of this lane's ray is over: merge into the path's closest-hit record

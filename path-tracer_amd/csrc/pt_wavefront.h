@@ -49,6 +49,8 @@ struct WfParams {
 	const float4* i0; const float4* i1; const float4* i2; const float4* i3;   // state set of the previous bounce (read)
 	float4* rad;              // [batch][npix]
 	int* queue[PT_MAX_BIG];   // per multi-node mesh: slots (in s0..s3) of the paths whose ray enters its root box
+	int* retry;               // slots of the rays the wide traversal (pt_wide.h) hands to the exact kernel; shared by the queues in turn
+	int use_retry;            // wf_traverse_coop_kernel: take the rays from `retry` instead of queue[slot]
 	int* counters;            // [bounce][1 + PT_MAX_BIG]: live count, queue counts (zeroed per batch)
 	PtxStats* stats;
 	int first_sample, batch;
@@ -62,6 +64,10 @@ struct WfParams {
 #define WF_CNT(wp, b, k) ((wp).counters[(b) * (1 + PT_MAX_BIG) + (k)])
 // dynamic work distribution of the traversal kernels: next unclaimed queue entry per (bounce, queue)
 #define WF_CUR(wp, b, k) ((wp).counters[(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) + (b) * (1 + PT_MAX_BIG) + (k)])
+// the same pair for the retry queue of (bounce, queue): its length and the next unclaimed entry
+#define WF_RCNT(wp, b, k) ((wp).counters[2 * (PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) + (b) * (1 + PT_MAX_BIG) + (k)])
+#define WF_RCUR(wp, b, k) ((wp).counters[3 * (PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) + (b) * (1 + PT_MAX_BIG) + (k)])
+#define WF_COUNTER_INTS (4 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG))
 
 // Queue feed of a persistent traversal wave. A wave claims CHUNK consecutive queue entries at a time
 // with one atomic (wave-uniform state: next/hi/exhausted), so every wave keeps all its lanes fed until
@@ -615,8 +621,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	const bool upper = lane >= 32;
 	int* stack = lds_stack + tid;
 	const DevObject& ob = sc.objects[obj_index];
-	const int n = WF_CNT(wp, wp.bounce, 1 + slot_index);
-	const int* __restrict__ queue = wp.queue[slot_index];
+	// the rays of this launch: the mesh's queue, or the retry queue the wide traversal left for it (pt_wide.h)
+	const int n = wp.use_retry ? WF_RCNT(wp, wp.bounce, 1 + slot_index) : WF_CNT(wp, wp.bounce, 1 + slot_index);
+	const int* __restrict__ queue = wp.use_retry ? wp.retry : wp.queue[slot_index];
 	const float4* __restrict__ nodes = sc.nodes;
 	const float4* __restrict__ pa = sc.tri_soa;
 	const float4* __restrict__ pe1 = sc.tri_soa + sc.num_tris;
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 	} else {
 		feed.next = feed.hi = 0;
 	}
-	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
+	int* cursor = wp.use_retry ? &WF_RCUR(wp, wp.bounce, 1 + slot_index) : &WF_CUR(wp, wp.bounce, 1 + slot_index);
 
 	// wave-uniform LDS byte address of this wave's staging area (leaf modes 5/6), as a scalar for the LDS-DMA base
 	const uint32_t nbase = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(
@@ -981,7 +988,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 					ts.intersects = true;
 					const float tt = __uint_as_float((uint32_t)(key >> 32));
 					if (tt < ts.tmin) {
-						ts.tmin = tt; ts.tri = leaf_first + (int)(uint32_t)key;
+						ts.tmin = tt; ts.tri = (int)(uint32_t)key;   // tri_grp carries device indices
 						if (FLAT == 9) { const float2 w = uvs[lane]; ts.bu = w.x; ts.bv = w.y; }
 					}
 				}

@@ -1,0 +1,263 @@
+// Wide traversal: the rays queued for a multi-node mesh walk a 4-WIDE tree over the groups of eight triangles
+// (pt_scene.h, wide_nodes) instead of the reference's binary KD tree, and the triangle tests run ASYNCHRONOUSLY
+// to the descent.
+//
+// Why. The cooperative kernel (pt_wavefront.h) follows the reference's tree node by node: 51 inner steps and 12
+// leaf visits per traversal, every one a dependent round trip through the vector-memory path, which is what that
+// kernel pays for (texture addresser 76 % busy, 33 of 64 lanes active). The RESULT of a traversal,
+// however, does not depend on the tree: rayIntersectsKDNodeLOOP (reference: src/intersect.cuh:119-212) returns the
+// smallest t over the triangles of all leaves it visits, and it visits every leaf that can hold a closer hit -
+// a box is only skipped when the ray misses it or enters it beyond the best t so far, and every box holds its
+// triangles with padding far above the rounding of either test (the argument, and the stress test, of the group
+// boxes: pt_wavefront.h, tools/grazing_stress.py). So the closest hit is the minimum over ALL triangles that pass
+// the reference's triangle test, and any conservative hierarchy finds it. What does depend on the tree is which
+// of two triangles with the SAME t (bit for bit) wins: the reference keeps the first it tests. Inside a leaf that
+// is run order, which the 64-bit keys reproduce (t bits << 32 | device index: run order); across leaves it is the
+// reference's visiting order. A ray whose best t is reached by triangles of two different 32-slot blocks is
+// therefore NOT decided here: it goes to the retry queue and is traversed again, from its untouched state, by the
+// exact kernel (wf_traverse_coop_kernel with wp.use_retry). The same exit serves rays whose stack would overflow.
+//
+// Structure (wave-uniform control flow):
+//   * one ray per lane walks wide nodes: one 64-B record = four child boxes in 8 bits relative to their union
+//     + four links (node index | 0x80000000 + group | -1). Children that are nodes are visited nearest first
+//     (sorted by entry distance, the others stacked with their distance, so that a stacked node behind the best
+//     hit is dropped at the pop without a fetch); children that are GROUPS become work units (owner lane, group)
+//     in the wave's list.
+//   * the lane does not wait for its units. Whenever >= DRAIN_MIN units have gathered the wave tests sixteen of
+//     them per step (four lanes per unit, two triangles per lane in packed FP32, the owner's ray by bpermute) and
+//     merges the hits into the owners' keys with LDS atomic minima; the owners then lower their culling bound.
+//   * once TURN_MIN lanes have finished, the remaining units are tested, finished lanes commit (closest object by
+//     distance, as the reference's loop over the objects: src/intersect.cuh:328-346) and idle lanes take new rays.
+#pragma once
+#include "pt_wavefront.h"
+
+#define WFW_UNIT_CAP 320
+#define WFW_WAVE_BYTES (64 * 8 + 64 * 8 + 64 * 4 + WFW_UNIT_CAP * 4)   /* keys, (u, v), flags, units */
+#define WFW_BYTES ((PT_BLOCK / 64) * WFW_WAVE_BYTES)
+#define WFW_STACK_ENTRY_BYTES 6                                         /* link (4) + entry distance as bf16 (2) */
+#define WFW_SCAP_MAX 12
+
+template <int FLAGS, int OCC, int CHUNK, int TURN_MIN, int DRAIN_MIN>
+__global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index, int scap) {
+	static_assert(DRAIN_MIN >= 16 && DRAIN_MIN <= 64 && 63 + 256 < WFW_UNIT_CAP, "the unit list must hold one more iteration's appends");
+	extern __shared__ int lds_stack[];
+	const int tid = threadIdx.x, lane = tid & 63;
+	int* stack = lds_stack + tid;                                                              // entry i at stack[i * PT_BLOCK]
+	unsigned short* sdist = reinterpret_cast<unsigned short*>(lds_stack + scap * PT_BLOCK) + tid;   // entry i at sdist[i * PT_BLOCK]
+	unsigned char* area = reinterpret_cast<unsigned char*>(lds_stack) + (size_t)scap * PT_BLOCK * WFW_STACK_ENTRY_BYTES + (tid >> 6) * WFW_WAVE_BYTES;
+	unsigned long long* keys = reinterpret_cast<unsigned long long*>(area);      // per lane: (t bits << 32 | triangle) of its best hit
+	float2* uvs = reinterpret_cast<float2*>(area + 64 * 8);                      // (u, v) of the triangle behind the key
+	uint32_t* flags = reinterpret_cast<uint32_t*>(area + 64 * 16);               // != 0: the best t was reached from two blocks
+	uint32_t* units = reinterpret_cast<uint32_t*>(area + 64 * 20);               // owner lane | group << 6
+	const int n = WF_CNT(wp, wp.bounce, 1 + slot_index);
+	const int* __restrict__ queue = wp.queue[slot_index];
+	const float4* __restrict__ wn = sc.wide_nodes;
+	const float4* __restrict__ tg = sc.tri_grp;
+	const int root = sc.wide_root[obj_index];
+	const unsigned long long lt = (1ull << lane) - 1ull;
+	uint64_t n_taken = 0, act = 0, tot = 0;
+	// PtxStats.x_*: visit iterations, lanes visiting in them, rays sent to the retry queue, stacked nodes dropped at the
+	// pop, unit steps, units, drains, commit / refill turns
+	uint64_t x_iters = 0, x_item = 0, x_retry = 0, x_drop = 0, x_usteps = 0, x_units = 0, x_drains = 0, x_turns = 0;
+
+	WaveFeed feed;
+	feed.exhausted = false;
+	feed.next = feed.hi = 0;
+	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
+
+	enum { IDLE = 0, DESCEND = 1, DONE = 2 };
+	int state = IDLE;
+	int path = 0, curr = 0, sp = 0, cur_obj_r = -1;
+	bool redo = false;
+	float cur_d = 0.0f, tmin = 0.0f;
+	f3 o = mk3(0.0f), d = mk3(1.0f), inv = mk3(1.0f);
+	int nunits = 0;   // wave-uniform
+
+	// the wave tests listed units, sixteen per step, newest first; all of them, or while full steps remain
+	auto unit_steps = [&](bool all) {
+		__builtin_amdgcn_wave_barrier();
+		if (FLAGS & PT_F_STATS) { if (lane == 0 && nunits > 0) x_drains++; }
+		while (nunits >= 16 || (all && nunits > 0)) {
+			const int take = nunits >= 16 ? 16 : nunits;
+			const int base = nunits - take;
+			const bool on = (lane >> 2) < take;
+			const uint32_t un = units[on ? base + (lane >> 2) : base];
+			const int owner = (int)(un & 63u);
+			const uint32_t grp = un >> 6;
+			const f3 bo = mk3(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+			const f3 bd = mk3(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128; x_usteps++; x_units += (uint64_t)take; } }
+			if (on) {   // uniform per quad
+				const float4* bp = tg + ((size_t)grp * PT_GRP_BLOCK_F4 + (lane & 3));
+				const float4 c0 = bp[0], c1 = bp[4], c2 = bp[8], c3 = bp[12], c4 = bp[16];
+				f3x2 va, e1, e2;
+				va.x = (v2f){c0.x, c0.y}; va.y = (v2f){c0.z, c0.w}; va.z = (v2f){c1.x, c1.y};
+				e1.x = (v2f){c1.z, c1.w}; e1.y = (v2f){c2.x, c2.y}; e1.z = (v2f){c2.z, c2.w};
+				e2.x = (v2f){c3.x, c3.y}; e2.y = (v2f){c3.z, c3.w}; e2.z = (v2f){c4.x, c4.y};
+				v2f t, u, v;
+				const uint32_t hb = tri_test_flat_x2(bo, bd, va, e1, e2, t, u, v);
+				if (FLAGS & PT_F_STATS) act += 2;
+				if (__ballot(hb != 0u) != 0ull) {
+					// a hit has t > 5e-8, so its bit pattern orders like its value; 0xffffffff = no hit
+					const uint32_t k0 = (hb & 1u) ? __float_as_uint(t.x) : 0xffffffffu;
+					const uint32_t k1 = (hb & 2u) ? __float_as_uint(t.y) : 0xffffffffu;
+					const uint32_t k = quad_min_u32(k0 < k1 ? k0 : k1);
+					const uint32_t s0 = __float_as_uint(c4.z), s1 = __float_as_uint(c4.w);   // device indices: run order inside a leaf
+					const uint32_t cand = quad_min_u32(umin3(k0 == k ? s0 : 0xffffffffu, k1 == k ? s1 : 0xffffffffu, 0xffffffffu));
+					const bool win0 = (k0 == k) & (s0 == cand), win1 = (k1 == k) & (s1 == cand);
+					if (k != 0xffffffffu && (win0 | win1)) {
+						const unsigned long long key = ((unsigned long long)k << 32) | (unsigned long long)cand;
+						const unsigned long long old = atomicMin(&keys[owner], key);
+						// the same t from another 32-slot block (= possibly another leaf): the reference's visiting
+						// order decides, which this kernel does not know
+						if ((uint32_t)(old >> 32) == k && (((uint32_t)old ^ cand) >> 5) != 0u) flags[owner] = 1u;
+						if (keys[owner] == key) uvs[owner] = win0 ? make_float2(u.x, v.x) : make_float2(u.y, v.y);
+					}
+				}
+			}
+			nunits = base;
+		}
+		__builtin_amdgcn_wave_barrier();
+		// owners lower their culling bound to the best t so far (a NaN pattern = no hit yet leaves it)
+		if (state == DESCEND) tmin = __builtin_fminf(tmin, __uint_as_float(reinterpret_cast<const uint32_t*>(keys)[2 * lane + 1]));
+	};
+
+	for (;;) {
+		const int n_desc = (int)__popcll(__ballot(state == DESCEND));
+		if (n_desc == 0 || (64 - n_desc >= TURN_MIN && !feed.exhausted)) {
+			// ---- turn: all listed units are tested, finished traversals commit, idle lanes take new rays ----
+			if (FLAGS & PT_F_STATS) { if (lane == 0) x_turns++; }
+			unit_steps(true);
+			bool again = false;
+			if (state == DONE) {
+				const unsigned long long key = keys[lane];
+				again = redo || flags[lane] != 0u;
+				if (!again && key != ~0ull) {
+					const float t = __uint_as_float((uint32_t)(key >> 32));
+					if (t < __builtin_huge_valf()) {
+						const f3 p = o + t * d;
+						const float dist = length3(p - o);
+						if (dist < cur_d || (dist == cur_d && cur_obj_r >= 0 && obj_index < cur_obj_r)) {
+							const float2 w = uvs[lane];
+							wp.s0[path].w = dist;
+							wp.s1[path].w = t;
+							wp.s2[path].w = __int_as_float(obj_index);
+							store_hit(wp.s3 + path, (int)(uint32_t)key, w.x, w.y);
+						}
+					}
+				}
+				state = IDLE;
+			}
+			{
+				const int slot = wave_append(&WF_RCNT(wp, wp.bounce, 1 + slot_index), again);
+				if (again) { wp.retry[slot] = path; if (FLAGS & PT_F_STATS) x_retry++; }
+			}
+			for (int attempt = 0; attempt < 2; ++attempt) {
+				const unsigned long long idle = __ballot(state == IDLE);
+				if (idle == 0ull) break;
+				if (feed.next >= feed.hi) {
+					if (feed.exhausted) break;
+					feed_claim(feed, cursor, n, CHUNK);
+					if (feed.exhausted) break;
+				}
+				const int mine = feed.next + (int)__popcll(idle & lt);
+				if (state == IDLE && mine < feed.hi) {
+					if (FLAGS & PT_F_STATS) n_taken++;
+					path = queue[mine];
+					const float4 a0 = wp.s0[path], a1 = wp.s1[path];
+					cur_obj_r = __float_as_int(wp.s2[path].w);
+					o = mk3(a0.x, a0.y, a0.z);
+					d = mk3(a1.x, a1.y, a1.z);
+					inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+					cur_d = a0.w;
+					tmin = __builtin_huge_valf();
+					curr = root;
+					sp = 0;
+					redo = false;
+					keys[lane] = ~0ull;
+					flags[lane] = 0u;
+					state = DESCEND;
+				}
+				feed.next += (int)__popcll(idle);
+			}
+			if (__ballot(state == DESCEND) == 0ull) break;   // queue drained, nothing in flight
+		}
+
+		// ---- one wide node per descending lane ----
+		if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; x_iters++; } if (state == DESCEND) { x_item++; act++; } }
+		uint32_t gh = 0;          // bit k: child k is a group and the ray touches its box
+		int gref0 = 0, gref1 = 0, gref2 = 0, gref3 = 0;
+		if (state == DESCEND) {
+			const float4* rec = wn + 4 * (size_t)curr;
+			const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3];
+			const float ax = (f0.x - o.x) * inv.x, ay = (f0.y - o.y) * inv.y, az = (f0.z - o.z) * inv.z;
+			const float sx = f0.w * inv.x, sy = f1.x * inv.y, sz = f1.y * inv.z;
+			const uint32_t w0 = __float_as_uint(f1.z), w1 = __float_as_uint(f1.w), w2 = __float_as_uint(f2.x),
+			               w3 = __float_as_uint(f2.y), w4 = __float_as_uint(f2.z), w5 = __float_as_uint(f2.w);
+			const int r0 = __float_as_int(f3.x), r1 = __float_as_int(f3.y), r2 = __float_as_int(f3.z), r3 = __float_as_int(f3.w);
+			gref0 = r0; gref1 = r1; gref2 = r2; gref3 = r3;
+#define WFW_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
+			// slab test on min / max (a NaN from 0 * inf drops out: that axis does not constrain); entry distance out
+			auto hit = [&](float lx, float ly, float lz, float hx, float hy, float hz, float& tn) {
+				const float tax = __builtin_fmaf(lx, sx, ax), tbx = __builtin_fmaf(hx, sx, ax);
+				const float tay = __builtin_fmaf(ly, sy, ay), tby = __builtin_fmaf(hy, sy, ay);
+				const float taz = __builtin_fmaf(lz, sz, az), tbz = __builtin_fmaf(hz, sz, az);
+				tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)), __builtin_fminf(taz, tbz));
+				const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)), __builtin_fmaxf(taz, tbz));
+				return !(tn > tf) && !(tf < 0.0f) && !(tn > tmin);
+			};
+			float n0, n1, n2, n3;
+			const bool h0 = hit(WFW_QB(w0, 0), WFW_QB(w0, 1), WFW_QB(w0, 2), WFW_QB(w0, 3), WFW_QB(w1, 0), WFW_QB(w1, 1), n0) & (r0 != -1);
+			const bool h1 = hit(WFW_QB(w1, 2), WFW_QB(w1, 3), WFW_QB(w2, 0), WFW_QB(w2, 1), WFW_QB(w2, 2), WFW_QB(w2, 3), n1) & (r1 != -1);
+			const bool h2 = hit(WFW_QB(w3, 0), WFW_QB(w3, 1), WFW_QB(w3, 2), WFW_QB(w3, 3), WFW_QB(w4, 0), WFW_QB(w4, 1), n2) & (r2 != -1);
+			const bool h3 = hit(WFW_QB(w4, 2), WFW_QB(w4, 3), WFW_QB(w5, 0), WFW_QB(w5, 1), WFW_QB(w5, 2), WFW_QB(w5, 3), n3) & (r3 != -1);
+#undef WFW_QB
+			gh = ((h0 & (r0 < 0)) ? 1u : 0u) | ((h1 & (r1 < 0)) ? 2u : 0u) | ((h2 & (r2 < 0)) ? 4u : 0u) | ((h3 & (r3 < 0)) ? 8u : 0u);
+			// inner children, nearest first: sort (entry distance with the slot in its two lowest bits)
+			auto skey = [](bool on, float tn, uint32_t slot) {
+				return on ? ((__float_as_uint(__builtin_fmaxf(tn, 0.0f)) & ~3u) | slot) : 0xffffffffu;
+			};
+			uint32_t k0 = skey(h0 & (r0 >= 0), n0, 0u), k1 = skey(h1 & (r1 >= 0), n1, 1u), k2 = skey(h2 & (r2 >= 0), n2, 2u), k3 = skey(h3 & (r3 >= 0), n3, 3u);
+#define WFW_CX(A, B) { const uint32_t lo_ = A < B ? A : B, hi_ = A < B ? B : A; A = lo_; B = hi_; }
+			WFW_CX(k0, k1) WFW_CX(k2, k3) WFW_CX(k0, k2) WFW_CX(k1, k3) WFW_CX(k1, k2)
+#undef WFW_CX
+			// the link in slot (key & 3): value selects (a lambda over references to r0..r3 made the compiler index them in scratch)
+#define WFW_LINK(KEY) ((((KEY) & 3u) == 3u) ? r3 : ((((KEY) & 3u) == 2u) ? r2 : ((((KEY) & 3u) == 1u) ? r1 : r0)))
+			if (k0 != 0xffffffffu) {
+				curr = WFW_LINK(k0);
+				const int more = (k1 != 0xffffffffu ? 1 : 0) + (k2 != 0xffffffffu ? 1 : 0) + (k3 != 0xffffffffu ? 1 : 0);
+				if (sp + more > scap) {
+					redo = true;          // the stack would overflow: the exact kernel takes this ray
+					state = DONE;
+				} else {
+					// farthest first, so that the nearest is popped first
+					if (k3 != 0xffffffffu) { stack[sp * PT_BLOCK] = WFW_LINK(k3); sdist[sp * PT_BLOCK] = (unsigned short)(k3 >> 16); ++sp; }
+					if (k2 != 0xffffffffu) { stack[sp * PT_BLOCK] = WFW_LINK(k2); sdist[sp * PT_BLOCK] = (unsigned short)(k2 >> 16); ++sp; }
+					if (k1 != 0xffffffffu) { stack[sp * PT_BLOCK] = WFW_LINK(k1); sdist[sp * PT_BLOCK] = (unsigned short)(k1 >> 16); ++sp; }
+				}
+			} else {
+				// pop; a stacked node the ray enters beyond the best hit so far is dropped (its distance was rounded
+				// DOWN to bf16, so nothing that could matter is dropped)
+				state = DONE;
+				while (sp > 0) {
+					--sp;
+					const float dn = __uint_as_float((uint32_t)sdist[sp * PT_BLOCK] << 16);
+					if (!(dn > tmin)) { curr = stack[sp * PT_BLOCK]; state = DESCEND; break; }
+					if (FLAGS & PT_F_STATS) x_drop++;
+				}
+			}
+		}
+#undef WFW_LINK
+		// append the touched groups to the wave's list (ballot + popcount prefix, no atomics)
+#define WFW_APPEND(BIT, REF) { \
+			const bool on_ = (gh & (BIT)) != 0u; \
+			const unsigned long long m_ = __ballot(on_); \
+			if (on_) units[nunits + (int)__popcll(m_ & lt)] = (uint32_t)lane | (((uint32_t)(REF) & 0x03ffffffu) << 6); \
+			nunits += (int)__popcll(m_); }
+		WFW_APPEND(1u, gref0) WFW_APPEND(2u, gref1) WFW_APPEND(4u, gref2) WFW_APPEND(8u, gref3)
+#undef WFW_APPEND
+		if (nunits >= DRAIN_MIN) unit_steps(false);
+	}
+	stats_flush(wp.stats, TraceCounters{0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
+	if (FLAGS & PT_F_STATS) exec_flush(wp.stats, x_iters, x_item, x_retry, x_drop, x_usteps, x_units, x_drains, x_turns);
+}

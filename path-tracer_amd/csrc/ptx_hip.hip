@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere in this file: without a HIP device every compute
 // entry point returns an error.
 #include "pt_unified.h"
+#include "pt_wide.h"
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -111,6 +112,12 @@ static int env_int(const char* name, int dflt) {
 #ifndef WF_CHUNK
 #define WF_CHUNK 128
 #endif
+#ifndef WFW_TURN_MIN
+#define WFW_TURN_MIN 8
+#endif
+#ifndef WFW_DRAIN_MIN
+#define WFW_DRAIN_MIN 32
+#endif
 #ifndef WF_ATHRESH
 #define WF_ATHRESH 28
 #endif
@@ -187,7 +194,7 @@ extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 extern "C" int ptx_render_cleanup(PtxCtx* ctx);
 
 static void wf_free(PtxCtx* c) {
-	void* ptrs[] = {c->wf.s0, c->wf.s1, c->wf.s2, c->wf.s3, c->wf_b[0], c->wf_b[1], c->wf_b[2], c->wf_b[3], c->wf.rad, c->wf.counters};
+	void* ptrs[] = {c->wf.s0, c->wf.s1, c->wf.s2, c->wf.s3, c->wf_b[0], c->wf_b[1], c->wf_b[2], c->wf_b[3], c->wf.rad, c->wf.counters, c->wf.retry};
 	for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i)
 		if (ptrs[i]) hipFree(ptrs[i]);
 	for (int k = 0; k < PT_MAX_BIG; ++k)
@@ -213,7 +220,8 @@ static int wf_ensure(PtxCtx* c, size_t paths, size_t rad, int queues) {
 	for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&c->wf_b[k], paths * sizeof(float4)));
 	HIP_TRY(hipMalloc((void**)&c->wf.rad, rad * sizeof(float4)));
 	for (int k = 0; k < queues; ++k) HIP_TRY(hipMalloc((void**)&c->wf.queue[k], paths * sizeof(int)));
-	HIP_TRY(hipMalloc((void**)&c->wf.counters, 2 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) * sizeof(int))); // counts + traversal cursors
+	HIP_TRY(hipMalloc((void**)&c->wf.counters, WF_COUNTER_INTS * sizeof(int))); // counts + traversal cursors, queues and retry queues
+	if (queues > 0) HIP_TRY(hipMalloc((void**)&c->wf.retry, paths * sizeof(int)));
 	c->wf_paths = paths;
 	c->wf_rad = rad;
 	c->wf_queues = queues;
@@ -262,6 +270,203 @@ static void free_scene_allocs(PtxScene* s) {
 	for (size_t i = 0; i < s->allocs.size(); ++i) hipFree(s->allocs[i]);
 	s->allocs.clear();
 }
+
+// Four boxes in 48 bytes (pt_scene.h, grp_qbox / wide nodes): the union U of the used boxes as origin and
+// step = extent / 255 per axis, then per box six bytes (lo.xyz rounded down, hi.xyz rounded up, in steps from U's
+// origin). The decoded box always contains the given one; an unused slot is (255, 255, 255, 0, 0, 0): never touched.
+static void quantise_boxes4(const float lo[4][3], const float hi[4][3], const bool used[4], float4 out[3]) {
+	double ulo[3] = {1e300, 1e300, 1e300}, uhi[3] = {-1e300, -1e300, -1e300};
+	for (int g = 0; g < 4; ++g) {
+		if (!used[g]) continue;
+		for (int k = 0; k < 3; ++k) { if (lo[g][k] < ulo[k]) ulo[k] = lo[g][k]; if (hi[g][k] > uhi[k]) uhi[k] = hi[g][k]; }
+	}
+	float org[3] = {0, 0, 0}, step[3] = {0, 0, 0};
+	unsigned char q[24];
+	for (int g = 0; g < 4; ++g) { q[6 * g] = q[6 * g + 1] = q[6 * g + 2] = 255; q[6 * g + 3] = q[6 * g + 4] = q[6 * g + 5] = 0; }
+	if (used[0] || used[1] || used[2] || used[3]) {
+		for (int k = 0; k < 3; ++k) {
+			org[k] = (float)ulo[k];
+			if ((double)org[k] > ulo[k]) org[k] = nextafterf(org[k], -INFINITY);
+			step[k] = (float)((uhi[k] - (double)org[k]) / 255.0);
+			// the largest code must reach the union's upper face in float arithmetic as the device decodes it
+			while (!((double)org[k] + 255.0 * (double)step[k] >= uhi[k])) step[k] = nextafterf(step[k], INFINITY);
+		}
+		for (int g = 0; g < 4; ++g) {
+			if (!used[g]) continue;
+			for (int k = 0; k < 3; ++k) {
+				int ql = 0, qh = 255;
+				if (step[k] > 0.0f) {
+					ql = (int)floor(((double)lo[g][k] - (double)org[k]) / (double)step[k]);
+					qh = (int)ceil(((double)hi[g][k] - (double)org[k]) / (double)step[k]);
+				}
+				ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+				qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+				while (ql > 0 && (double)org[k] + (double)ql * (double)step[k] > (double)lo[g][k]) --ql;
+				while (qh < 255 && (double)org[k] + (double)qh * (double)step[k] < (double)hi[g][k]) ++qh;
+				q[6 * g + k] = (unsigned char)ql;
+				q[6 * g + 3 + k] = (unsigned char)qh;
+			}
+		}
+	}
+	uint32_t w[6];
+	memcpy(w, q, 24);
+	out[0] = make_float4(org[0], org[1], org[2], step[0]);
+	out[1] = make_float4(step[1], step[2], as_float((int32_t)w[0]), as_float((int32_t)w[1]));
+	out[2] = make_float4(as_float((int32_t)w[2]), as_float((int32_t)w[3]), as_float((int32_t)w[4]), as_float((int32_t)w[5]));
+}
+
+
+// ---- wide tree (pt_scene.h, wide_nodes; traversed by pt_wide.h) -------------------------------------------------
+// A 4-wide bounding-volume hierarchy over the GROUPS of eight triangles, collapsed from the reference's binary
+// KD tree: a wide node's children are found by opening, largest surface first, the inner KD nodes / leaves among
+// them until four are reached. Boxes are unions of group boxes (which hold their triangles with the usual
+// padding), stored in the 8-bit form of grp_qbox. Leaves of more than four groups get intermediate nodes over
+// contiguous quarters of their (sorted) group list.
+struct WideItem {
+	int kind;        // 0 = KD node (scene-global index), 1 = run of `n` consecutive groups from global group `a`
+	int a, n;
+	float lo[3], hi[3];
+};
+
+struct WideBuilder {
+	const std::vector<float4>& nodes;       // packed KD records of the whole scene
+	const std::vector<float4>& grp_boxes;
+	std::vector<float4>& out;               // 4 float4 per wide node
+	std::vector<float> kd_box;              // per KD node of the object: 6 floats, filled bottom-up
+	int base = 0;                           // first KD node of the object
+	int max_stack = 0;                      // most entries a traversal can hold at once
+
+	static float area(const WideItem& it) {
+		const float dx = it.hi[0] - it.lo[0], dy = it.hi[1] - it.lo[1], dz = it.hi[2] - it.lo[2];
+		return dx * dy + dy * dz + dz * dx;
+	}
+	void group_box(int g, float lo[3], float hi[3]) const {
+		const float4 l = grp_boxes[(size_t)g * 2], h = grp_boxes[(size_t)g * 2 + 1];
+		lo[0] = l.x; lo[1] = l.y; lo[2] = l.z; hi[0] = h.x; hi[1] = h.y; hi[2] = h.z;
+	}
+	WideItem run_item(int g0, int n) const {
+		WideItem it; it.kind = 1; it.a = g0; it.n = n;
+		for (int k = 0; k < 3; ++k) { it.lo[k] = INFINITY; it.hi[k] = -INFINITY; }
+		for (int g = g0; g < g0 + n; ++g) {
+			float lo[3], hi[3];
+			group_box(g, lo, hi);
+			for (int k = 0; k < 3; ++k) { if (lo[k] < it.lo[k]) it.lo[k] = lo[k]; if (hi[k] > it.hi[k]) it.hi[k] = hi[k]; }
+		}
+		return it;
+	}
+	// number of groups of a KD leaf record (0 for an empty leaf)
+	static int leaf_groups(const float4* rec) { const int n = as_int(rec[3].w); return n > 0 ? (n + 7) / 8 : 0; }
+	bool kd_is_leaf(int ni) const { const float4* r = &nodes[(size_t)ni * 4]; return as_int(r[3].x) == -1 && as_int(r[3].y) == -1; }
+
+	// boxes of the KD nodes as unions of the group boxes beneath (empty subtrees: lo > hi)
+	void fill_boxes(int root, int num_nodes) {
+		kd_box.assign((size_t)num_nodes * 6, 0.0f);
+		std::vector<std::pair<int, int> > todo;   // (node, phase)
+		todo.push_back(std::make_pair(root, 0));
+		while (!todo.empty()) {
+			const int ni = todo.back().first, phase = todo.back().second;
+			todo.pop_back();
+			const float4* r = &nodes[(size_t)ni * 4];
+			float* b = &kd_box[(size_t)(ni - base) * 6];
+			if (kd_is_leaf(ni)) {
+				const int ng = leaf_groups(r);
+				for (int k = 0; k < 3; ++k) { b[k] = INFINITY; b[3 + k] = -INFINITY; }
+				if (ng > 0) { const WideItem it = run_item(4 * as_int(r[0].x), ng); for (int k = 0; k < 3; ++k) { b[k] = it.lo[k]; b[3 + k] = it.hi[k]; } }
+				continue;
+			}
+			const int ch[2] = {as_int(r[3].x), as_int(r[3].y)};
+			if (phase == 0) {
+				todo.push_back(std::make_pair(ni, 1));
+				for (int c = 0; c < 2; ++c) if (ch[c] >= 0) todo.push_back(std::make_pair(ch[c], 0));
+			} else {
+				for (int k = 0; k < 3; ++k) { b[k] = INFINITY; b[3 + k] = -INFINITY; }
+				for (int c = 0; c < 2; ++c) if (ch[c] >= 0) {
+					const float* cb = &kd_box[(size_t)(ch[c] - base) * 6];
+					for (int k = 0; k < 3; ++k) { if (cb[k] < b[k]) b[k] = cb[k]; if (cb[3 + k] > b[3 + k]) b[3 + k] = cb[3 + k]; }
+				}
+			}
+		}
+	}
+	bool kd_empty(int ni) const { const float* b = &kd_box[(size_t)(ni - base) * 6]; return !(b[0] <= b[3]); }
+	// a KD node as an item: leaves become their run of groups, chains of single children are followed; a subtree
+	// without triangles becomes the empty run (n = 0), which children() drops
+	WideItem kd_item(int ni) const {
+		for (;;) {
+			if (ni < 0 || kd_empty(ni)) return run_item(0, 0);
+			const float4* r = &nodes[(size_t)ni * 4];
+			if (kd_is_leaf(ni)) return run_item(4 * as_int(r[0].x), leaf_groups(r));
+			const int l = as_int(r[3].x), rr = as_int(r[3].y);
+			const bool hl = l >= 0 && !kd_empty(l), hr = rr >= 0 && !kd_empty(rr);
+			if (hl && hr) break;
+			ni = hl ? l : rr;
+		}
+		WideItem it; it.kind = 0; it.a = ni; it.n = 0;
+		const float* b = &kd_box[(size_t)(ni - base) * 6];
+		for (int k = 0; k < 3; ++k) { it.lo[k] = b[k]; it.hi[k] = b[3 + k]; }
+		return it;
+	}
+	static bool is_empty(const WideItem& it) { return it.kind == 1 && it.n == 0; }
+	static bool is_group(const WideItem& it) { return it.kind == 1 && it.n == 1; }
+	// the children of an item that is not a single group (2..4 of them)
+	void children(const WideItem& it, std::vector<WideItem>& ch) const {
+		ch.clear();
+		if (it.kind == 0) {
+			const float4* r = &nodes[(size_t)it.a * 4];
+			const WideItem l = kd_item(as_int(r[3].x)), rr = kd_item(as_int(r[3].y));
+			if (!is_empty(l)) ch.push_back(l);
+			if (!is_empty(rr)) ch.push_back(rr);
+		} else if (it.n <= 4) {
+			for (int g = 0; g < it.n; ++g) ch.push_back(run_item(it.a + g, 1));
+		} else {
+			const int parts = 4;
+			int at = it.a;
+			for (int p = 0; p < parts; ++p) {
+				const int len = (it.n - (at - it.a) + (parts - p) - 1) / (parts - p);
+				ch.push_back(run_item(at, len));
+				at += len;
+			}
+		}
+	}
+	// emits the wide node over `list` (1..4 items) and everything beneath; returns its index
+	int emit(std::vector<WideItem> list, int stack_above) {
+		std::vector<WideItem> ch;
+		for (;;) {
+			int pick = -1;
+			for (size_t i = 0; i < list.size(); ++i) {
+				if (is_group(list[i])) continue;
+				children(list[i], ch);
+				if (list.size() - 1 + ch.size() > 4) continue;
+				if (pick < 0 || area(list[i]) > area(list[(size_t)pick])) pick = (int)i;
+			}
+			if (pick < 0) break;
+			children(list[(size_t)pick], ch);
+			list.erase(list.begin() + pick);
+			list.insert(list.end(), ch.begin(), ch.end());
+		}
+		const int idx = (int)(out.size() / 4);
+		out.resize(out.size() + 4, make_float4(0, 0, 0, 0));
+		float lo[4][3], hi[4][3];
+		bool used[4] = {false, false, false, false};
+		int32_t ref[4] = {-1, -1, -1, -1};
+		int inner = 0;
+		for (size_t i = 0; i < list.size(); ++i) if (!is_group(list[i])) ++inner;
+		// the traversal follows one inner child and stacks the others
+		const int below = stack_above + (inner > 0 ? inner - 1 : 0);
+		if (below > max_stack) max_stack = below;
+		for (size_t i = 0; i < list.size(); ++i) {
+			used[i] = true;
+			for (int k = 0; k < 3; ++k) { lo[i][k] = list[i].lo[k]; hi[i][k] = list[i].hi[k]; }
+			if (is_group(list[i])) ref[i] = (int32_t)(0x80000000u | (uint32_t)list[i].a);
+			else { children(list[i], ch); ref[i] = emit(ch, below); }
+		}
+		float4 q[3];
+		quantise_boxes4(lo, hi, used, q);
+		out[(size_t)idx * 4 + 0] = q[0]; out[(size_t)idx * 4 + 1] = q[1]; out[(size_t)idx * 4 + 2] = q[2];
+		out[(size_t)idx * 4 + 3] = make_float4(as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]));
+		return idx;
+	}
+};
+
 
 extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** out) {
 	if (!ctx || !d || !out) return fail(PTX_E_INVALID, "ptx_scene_upload: NULL argument");
@@ -425,7 +630,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 							float4& q = grp_tris[gi * PT_GRP_BLOCK_F4 + (size_t)(c / 2) * 4 + ln];
 							(&q.x)[(c % 2) * 2 + hi] = comp[c];
 						}
-						(&grp_tris[gi * PT_GRP_BLOCK_F4 + 16 + ln].x)[2 + hi] = as_float(k);
+						(&grp_tris[gi * PT_GRP_BLOCK_F4 + 16 + ln].x)[2 + hi] = as_float(first_dev + k);   // device index of the triangle: run order
 						float4& lo = grp_boxes[gi * 2];
 						float4& up = grp_boxes[gi * 2 + 1];
 						for (int c = 0; c < 3; ++c) {
@@ -505,52 +710,36 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	// and each box in 8-bit steps of it, rounded outward.
 	std::vector<float4> qboxes(grp_boxes.size() / 8 * 3, make_float4(0, 0, 0, 0));
 	for (size_t b = 0; b < grp_boxes.size() / 8; ++b) {
-		double ulo[3] = {1e300, 1e300, 1e300}, uhi[3] = {-1e300, -1e300, -1e300};
+		float lo[4][3], hi[4][3];
 		bool used[4];
 		for (int g = 0; g < 4; ++g) {
-			const float4 lo = grp_boxes[(4 * b + g) * 2], hi = grp_boxes[(4 * b + g) * 2 + 1];
-			used[g] = lo.x <= hi.x;   // unused slots hold (+inf, -inf)
-			if (!used[g]) continue;
-			const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
-			for (int k = 0; k < 3; ++k) { if (l[k] < ulo[k]) ulo[k] = l[k]; if (h[k] > uhi[k]) uhi[k] = h[k]; }
+			const float4 l = grp_boxes[(4 * b + g) * 2], h = grp_boxes[(4 * b + g) * 2 + 1];
+			used[g] = l.x <= h.x;   // unused slots hold (+inf, -inf)
+			lo[g][0] = l.x; lo[g][1] = l.y; lo[g][2] = l.z; hi[g][0] = h.x; hi[g][1] = h.y; hi[g][2] = h.z;
 		}
-		float org[3] = {0, 0, 0}, step[3] = {0, 0, 0};
-		unsigned char q[24];
-		for (int g = 0; g < 4; ++g) { q[6 * g] = q[6 * g + 1] = q[6 * g + 2] = 255; q[6 * g + 3] = q[6 * g + 4] = q[6 * g + 5] = 0; }
-		if (used[0] || used[1] || used[2] || used[3]) {
-			for (int k = 0; k < 3; ++k) {
-				org[k] = (float)ulo[k];
-				if ((double)org[k] > ulo[k]) org[k] = nextafterf(org[k], -INFINITY);
-				step[k] = (float)((uhi[k] - (double)org[k]) / 255.0);
-				// the largest code must reach the union's upper face in float arithmetic as the device decodes it
-				while (!((double)org[k] + 255.0 * (double)step[k] >= uhi[k])) step[k] = nextafterf(step[k], INFINITY);
-			}
-			for (int g = 0; g < 4; ++g) {
-				if (!used[g]) continue;
-				const float4 lo = grp_boxes[(4 * b + g) * 2], hi = grp_boxes[(4 * b + g) * 2 + 1];
-				const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
-				for (int k = 0; k < 3; ++k) {
-					int ql = 0, qh = 255;
-					if (step[k] > 0.0f) {
-						ql = (int)floor(((double)l[k] - (double)org[k]) / (double)step[k]);
-						qh = (int)ceil(((double)h[k] - (double)org[k]) / (double)step[k]);
-					}
-					ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
-					qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
-					while (ql > 0 && (double)org[k] + (double)ql * (double)step[k] > (double)l[k]) --ql;
-					while (qh < 255 && (double)org[k] + (double)qh * (double)step[k] < (double)h[k]) ++qh;
-					q[6 * g + k] = (unsigned char)ql;
-					q[6 * g + 3 + k] = (unsigned char)qh;
-				}
-			}
-		}
-		uint32_t w[6];
-		memcpy(w, q, 24);
-		qboxes[3 * b + 0] = make_float4(org[0], org[1], org[2], step[0]);
-		qboxes[3 * b + 1] = make_float4(step[1], step[2], as_float((int32_t)w[0]), as_float((int32_t)w[1]));
-		qboxes[3 * b + 2] = make_float4(as_float((int32_t)w[2]), as_float((int32_t)w[3]), as_float((int32_t)w[4]), as_float((int32_t)w[5]));
+		quantise_boxes4(lo, hi, used, &qboxes[3 * b]);
 	}
 	if (qboxes.empty()) qboxes.assign(3, make_float4(0, 0, 0, 0));
+	// Wide trees (pt_scene.h, wide_nodes): one per multi-node mesh, roots per object
+	std::vector<float4> wide;
+	std::vector<int32_t> wide_root((size_t)(d->num_objects > 0 ? d->num_objects : 1), -1);
+	int wide_stack = 1;
+	for (int oi = 0; oi < d->num_objects; ++oi) {
+		const DevObject& dv = objs[(size_t)oi];
+		if (dv.type != PTX_OBJ_MESH || dv.root_node < 0) continue;
+		WideBuilder wb{nodes, grp_boxes, wide};
+		wb.base = dv.first_node;
+		wb.fill_boxes(dv.root_node, d->objects[oi].num_nodes);
+		const WideItem root = wb.kd_item(dv.root_node);
+		std::vector<WideItem> top;
+		if (WideBuilder::is_group(root)) top.push_back(root);
+		else if (!WideBuilder::is_empty(root)) wb.children(root, top);
+		wide_root[(size_t)oi] = wb.emit(top, 0);
+		if (wb.max_stack > wide_stack) wide_stack = wb.max_stack;
+	}
+	if (wide.empty()) wide.assign(4, make_float4(0, 0, 0, 0));
+	if (wide.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu wide nodes; the limit is 2^26", wide.size() / 4);
+	if (grp_boxes.size() / 2 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu triangle groups; the limit is 2^26", grp_boxes.size() / 2);
 	// the traversal kernels address node / leaf-half records with 32-bit byte offsets from the array base
 	if (nodes.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu KD node and leaf-half records; the limit is 2^26", nodes.size() / 4);
 	HIP_TRY(hipSetDevice(ctx->device));
@@ -588,6 +777,8 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	UP(grp_tris, tri_grp)
 	UP(grp_boxes, grp_box)
 	UP(qboxes, grp_qbox)
+	UP(wide, wide_nodes)
+	UP(wide_root, wide_root)
 	UP(shade, tri_shade)
 	UP(mats, materials)
 #undef UP
@@ -610,6 +801,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	s->dev.num_objects = d->num_objects;
 	s->dev.stack_entries = scene_max_depth < 1 ? 1 : scene_max_depth;
 	s->dev.half_base = (int32_t)half_base;
+	s->dev.wide_stack = wide_stack;
 	hipError_t e = hipStreamSynchronize(ctx->stream); // host vectors die at return
 	if (e != hipSuccess) { free_scene_allocs(s); delete s; return fail(PTX_E_HIP, "scene upload: %s", hipGetErrorString(e)); }
 	*out = s;
@@ -726,11 +918,26 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3090)   11: mode 5 (3150)
 #define UNI(F, O, C, U) hipLaunchKernelGGL((wf_traverse_unified_kernel<F, O, C, U>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + WF_UNI_BYTES, ctx->stream, scene->dev, wp, obj, k)
 	//   12: unified item loop (pt_unified.h): descent and group boxes in one loop, units tested once 16 have gathered
+	//   0 / 14: wide traversal (pt_wide.h) + the exact kernel (leaf mode 9) over its retry queue; 14 counts with its own twin, 0 with the exact kernel
+	//   15: leaf mode 9 alone (the default before the wide traversal)
+	const int scap = scene->dev.wide_stack < WFW_SCAP_MAX ? scene->dev.wide_stack : WFW_SCAP_MAX;
+	const size_t wide_lds = (size_t)scap * PT_BLOCK * WFW_STACK_ENTRY_BYTES + WFW_BYTES;
+#define WIDE(F) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, 5, WF_CHUNK, WFW_TURN_MIN, WFW_DRAIN_MIN>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap)
 	const bool uni_fits = lds + WF_UNI_BYTES <= 64 * 1024;
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
+	// the exact kernel for the rays the wide traversal could not decide (equal t from two leaves, stack overflow)
+	auto exact_retry = [&]() {
+		WfParams wr = wp;
+		wr.use_retry = 1;
+		const WfParams& wp = wr;   // the launch macros name `wp`
+		if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 9);
+		else if (stage_fits) COOP(0, 5, 64, 32, 4);
+		else COOP(0, 4, 64, 32, 3);
+	};
 	if (collect_stats) {
-		if (ctx->trav_variant == 12 && uni_fits) UNI(PT_F_STATS, 5, 128, 16);
+		if (ctx->trav_variant == 14) { WIDE(PT_F_STATS); exact_retry(); }
+		else if (ctx->trav_variant == 12 && uni_fits) UNI(PT_F_STATS, 5, 128, 16);
 		else if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
 		else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
 		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
@@ -752,12 +959,17 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		case 11: if (grp_fits) COOP(0, 4, 128, 28, 5); else COOP(0, 4, 64, 32, 3); break;
 		case 13: if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 6); else COOP(0, 4, 64, 32, 3); break;
 		case 12: if (uni_fits) UNI(0, 5, 128, 16); else COOP(0, 4, 64, 32, 3); break;
-		default:
+		case 15:
 			if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 9);
 			else if (stage_fits) COOP(0, 5, 64, 32, 4);
 			else COOP(0, 4, 64, 32, 3);
 			break;
+		default:
+			WIDE(0);
+			exact_retry();
+			break;
 	}
+#undef WIDE
 #undef TRAV
 #undef COOP
 #undef UNI
@@ -820,7 +1032,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		wp.n_total = (int)(npt * (size_t)b);
 		wp.k0 = k0; wp.k1 = k1;
 		wp.num_big = scene->num_big;
-		HIP_TRY(hipMemsetAsync(wp.counters, 0, 2 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) * sizeof(int), ctx->stream));
+		HIP_TRY(hipMemsetAsync(wp.counters, 0, WF_COUNTER_INTS * sizeof(int), ctx->stream));
 		for (int bounce = 0; bounce <= maxb; ++bounce) {
 			wp.bounce = bounce;
 			wp.is_last = bounce == maxb ? 1 : 0;
@@ -1039,15 +1251,16 @@ extern "C" int ptx_trace_rays_queued(PtxCtx* ctx, const PtxScene* scene, int n, 
 	if (slot < 0) return fail(PTX_E_INVALID, "ptx_trace_rays_queued: object %d is not a multi-node mesh with a traversal queue", object);
 	if (n == 0) return PTX_OK;
 	HIP_TRY(hipSetDevice(ctx->device));
-	DevBuf d_o, d_d, d_h, d_s, d_q, d_c;
+	DevBuf d_o, d_d, d_h, d_s, d_q, d_c, d_r;
 	const size_t rb = (size_t)n * 3 * sizeof(float);
-	const size_t ncnt = 2 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG);
+	const size_t ncnt = WF_COUNTER_INTS;
 	HIP_TRY(hipMalloc(&d_o.p, rb));
 	HIP_TRY(hipMalloc(&d_d.p, rb));
 	HIP_TRY(hipMalloc(&d_h.p, (size_t)n * sizeof(PtxHit)));
 	HIP_TRY(hipMalloc(&d_s.p, (size_t)n * 4 * sizeof(float4)));
 	HIP_TRY(hipMalloc(&d_q.p, (size_t)n * sizeof(int)));
 	HIP_TRY(hipMalloc(&d_c.p, ncnt * sizeof(int)));
+	HIP_TRY(hipMalloc(&d_r.p, (size_t)n * sizeof(int)));
 	HIP_TRY(hipMemcpyAsync(d_o.p, origins, rb, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(hipMemcpyAsync(d_d.p, dirs, rb, hipMemcpyHostToDevice, ctx->stream));
 	HIP_TRY(hipMemsetAsync(d_c.p, 0, ncnt * sizeof(int), ctx->stream));
@@ -1056,6 +1269,7 @@ extern "C" int ptx_trace_rays_queued(PtxCtx* ctx, const PtxScene* scene, int n, 
 	wp.s0 = (float4*)d_s.p; wp.s1 = wp.s0 + n; wp.s2 = wp.s1 + n; wp.s3 = wp.s2 + n;
 	wp.queue[slot] = (int*)d_q.p;
 	wp.counters = (int*)d_c.p;
+	wp.retry = (int*)d_r.p;
 	wp.stats = ctx->d_stats;
 	wp.n_total = n;
 	wp.num_big = scene->num_big;
