@@ -13,10 +13,11 @@ collective) and ONE all-reduce (RCCL) of the float accumulation buffers closes t
 The timed region ends when the accumulated buffer is resident on rank 0's HOST.
 
 Prints one JSON line (rank 0) with the contract fields plus
-  "roofline"      for the dominant kernel, wf_traverse_coop_kernel (KD traversal + ray/triangle tests of
-                  the rays queued for a multi-node mesh). Neither HBM nor MFMA bounds it (the 21 MB tree
-                  is cache-resident, nothing is a dense contraction), so `bound` names the unit that
-                  does: the larger of the vector-memory front end (texture-addresser busy) and VALU
+  "roofline"      for the dominant kernel class of this run: wf_traverse_wide_kernel (traversal + ray/triangle
+                  tests of the rays queued for a multi-node mesh) or wf_segment_kernel (ray generation, shading,
+                  cheap objects); since the wide traversal they take about the same time, the other one is reported
+                  under "other_kernel". Neither HBM nor MFMA bounds them (the trees are cache-resident, nothing
+                  is a dense contraction), so `bound` names the unit that does: the larger of the vector-memory front end (texture-addresser busy) and VALU
                   issue, from the committed PMC passes (profiles/r02_pmc.json, recomputable from them
                   and profiles/r02_kernel_stats.csv alone) rescaled to the launch time measured live
                   here with HIP event pairs on the library's stream. `executed` = bytes and flops the
@@ -57,12 +58,11 @@ def logical_bytes_and_flops(st):
 
 
 def executed_bytes_and_flops(st):
-    """What the traversal kernel itself requests and computes (counting twin of the default kernel, PtxStats.x_*):
-    a 64-B node record and one packed two-box test per descending lane and iteration; the four group boxes of a
-    leaf (48 B in their quantised form, four slab tests) per leaf visit; 320 B and eight triangle tests per work
-    unit; per traversal the queue entry, ray state in and the closest-hit record out (64 B)."""
-    b = 64 * st["x_item_lanes"] + 48 * st["x_half_lanes"] + 320 * st["x_units"] + 64 * st["trav_rays"]
-    f = 22 * (2 * st["x_item_lanes"] + 4 * st["x_half_lanes"]) + 48 * 8 * st["x_units"]
+    """What the wide traversal kernel itself requests and computes (its counting twin, variant 14, PtxStats.x_*):
+    a 64-B wide-node record and four slab tests (22 flop each) per node visit; 320 B and eight triangle tests
+    (48 flop each) per work unit; per traversal the queue entry, ray state in and the closest-hit record out (64 B)."""
+    b = 64 * st["x_item_lanes"] + 320 * st["x_units"] + 64 * st["trav_rays"]
+    f = 22 * 4 * st["x_item_lanes"] + 48 * 8 * st["x_units"]
     return b, f
 
 
@@ -206,50 +206,55 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline leg (rank 0): counters of the SAME samples from the counting twin of the default kernel -------
-    pt.check(L.ptx_stats_reset(ctx))
-    for i in range(args.warmup, args.warmup + args.steps):
-        pt.check(L.ptx_render_samples(ctx, scene, (i * world + rank) * spp, spp, args.seed, 1))
-    pt.check(L.ptx_render_sync(ctx))
-    cst = pt.PtxStats()
-    pt.check(L.ptx_stats_get(ctx, C.byref(cst)))
-    cd = cst.as_dict()
-    # the dominant kernel: the traversal of the multi-node meshes where the scene has one (the headline scene:
-    # 71 % of a step), else the segment kernel (sphere / single-leaf scenes have no traversal launches at all)
-    trav_dominant = trav_n.value > 0 and trav_ms.value >= seg_ms.value
-    n_launch = max(1, trav_n.value if trav_dominant else seg_n.value)
-    launch_ms = float(trav_ms.value if trav_dominant else seg_ms.value) / n_launch   # HIP event pairs around every launch
-    launch_s = max(launch_ms * 1e-3, 1e-12)
+    # ---- roofline leg (rank 0): counters of the SAME samples ---------------------------------------------------
+    # two counting passes: the default kernels' exact twin gives the REFERENCE algorithm's counts (logical), the wide
+    # traversal's own counting twin (variant 14) what that kernel executes (PtxStats.x_*)
+    def counting_pass(variant):
+        pt.check(L.ptx_ctx_tune(ctx, b"trav_variant", variant))
+        pt.check(L.ptx_stats_reset(ctx))
+        for i in range(args.warmup, args.warmup + args.steps):
+            pt.check(L.ptx_render_samples(ctx, scene, (i * world + rank) * spp, spp, args.seed, 1))
+        pt.check(L.ptx_render_sync(ctx))
+        st = pt.PtxStats()
+        pt.check(L.ptx_stats_get(ctx, C.byref(st)))
+        pt.check(L.ptx_ctx_tune(ctx, b"trav_variant", -1))
+        return st.as_dict()
+
+    cd = counting_pass(-1)
+    xd = counting_pass(14)
     tr = max(1, cd["trav_rays"])
-    kernel = "wf_traverse_coop_kernel<0,4,128,28,9>" if trav_dominant else "wf_segment_kernel<0>"
-    xb, xf = executed_bytes_and_flops(cd)
+    xb, xf = executed_bytes_and_flops(xd)
     lb, lf = logical_bytes_and_flops(cd)
-    x_tflops = xf / n_launch / launch_s / 1e12 if trav_dominant else 0.0
-    x_gbs = xb / n_launch / launch_s / 1e9 if trav_dominant else 0.0
-    pmc = load_pmc(kernel)
-    bound, achieved, peak, unit, frac, traffic, pmc_view = "valu", x_tflops, VALU_PEAK_TFLOPS, "TFLOP/s", x_tflops / VALU_PEAK_TFLOPS, None, None
-    if pmc and pmc.get("derived", {}).get("ta_busy_frac") and pmc.get("avg_ns_kernel_trace"):
+
+    def kernel_view(kernel, class_ms, class_n):
+        """bound / achieved / peak / frac of one kernel class: the larger of texture-addresser busy and VALU issue at
+        2 cycles per wave64 instruction, from the committed PMC passes rescaled to the launch time measured live."""
+        n_launch = max(1, class_n)
+        launch_ms = float(class_ms) / n_launch
+        launch_s = max(launch_ms * 1e-3, 1e-12)
+        view = {"kernel": kernel, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                "launch_ms": round(launch_ms, 4), "launches": class_n,
+                "share_of_step": round(float(class_ms) / max(1e-9, float(kernel_ms.value)), 4), "pmc": None}
+        pmc = load_pmc(kernel)
+        if not (pmc and pmc.get("derived", {}).get("ta_busy_frac") and pmc.get("avg_ns_kernel_trace")):
+            return view
         d, c, nd = pmc["derived"], pmc["counters"], pmc["dispatches"]
-        # Which unit binds: the larger of the vector-memory front end (texture addresser busy) and VALU issue at
-        # the guide's 2 cycles per wave64 instruction. The counters are the committed profile's; the launch time
-        # is this run's, so each fraction is rescaled by profile launch time / live launch time.
         # (the committed passes are of the headline workload: for another scene the fractions are only indicative)
         scale = pmc["avg_ns_kernel_trace"] * 1e-6 / launch_ms if launch_ms > 0 else 1.0
         ta = d["ta_busy_frac"] * scale
         valu2 = d.get("valu_issue_frac_2cyc", 0.0) * scale
         clock = d.get("clock_ghz", PEAK_CLOCK_GHZ)
-        traffic = round(d["hbm_side_bytes_per_launch"]) if "hbm_side_bytes_per_launch" in d else None
+        view["traffic"] = round(d["hbm_side_bytes_per_launch"]) if "hbm_side_bytes_per_launch" in d else None
         if ta >= valu2:
-            bound, unit = "vmem", "Gcycle/s busy, summed over the 256 texture addressers (one per CU)"
-            achieved = c["TA_TA_BUSY_sum"] / nd / launch_s / 1e9
-            peak = CUS * clock
+            view["bound"], view["unit"] = "vmem", "Gcycle/s busy, summed over the 256 texture addressers (one per CU)"
+            achieved, peak = c["TA_TA_BUSY_sum"] / nd / launch_s / 1e9, CUS * clock
         else:
-            bound, unit = "valu-issue", "G wave64 VALU instructions/s"
-            achieved = c["SQ_INSTS_VALU"] / nd / launch_s / 1e9
-            peak = SIMDS * clock / 2.0
-        frac = achieved / peak
+            view["bound"], view["unit"] = "valu-issue", "G wave64 VALU instructions/s (2 cycles each per SIMD)"
+            achieved, peak = c["SQ_INSTS_VALU"] / nd / launch_s / 1e9, SIMDS * clock / 2.0
+        view["achieved"], view["peak"], view["frac"] = round(achieved, 3), round(peak, 3), round(achieved / peak, 4)
         l2_gbs = c.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0 / nd / launch_s / 1e9
-        pmc_view = {
+        hbm_gbs = d.get("hbm_side_bytes_per_launch", 0.0) / launch_s / 1e9
+        view["pmc"] = {
             "source": PMC_FILE + " + profiles/r02_kernel_stats.csv (tools/profile_r02.sh; launch time there "
                       f"{pmc['avg_ns_kernel_trace'] * 1e-6:.3f} ms, here {launch_ms:.3f} ms)",
             "clock_ghz": round(clock, 3),
@@ -259,38 +264,58 @@ def main():
             "active_lanes_per_valu_inst": round(d.get("active_lanes_per_valu_inst", 0.0), 2),
             "valu_useful_frac": round(valu2 * d.get("active_lanes_per_valu_inst", 0.0) / 64.0, 4),
             "l1_to_l2_read": {"achieved": round(l2_gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2_gbs / L2_PEAK_GBS, 4)},
-            "l1_tag_lookups_per_traversal": round(c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / nd / max(1.0, cd["trav_rays"] / n_launch), 1) if trav_dominant else None,
-            "vmem_wave_instructions_per_64_traversals": round((c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0)) / nd / max(1.0, cd["trav_rays"] / n_launch) * 64.0, 1) if trav_dominant else None,
+            "hbm_side": {"achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4)},
+            "vmem_wave_instructions_per_launch": round((c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0)) / nd),
+            "valu_wave_instructions_per_launch": round(c.get("SQ_INSTS_VALU", 0.0) / nd),
             "l2_hit_frac": round(d.get("l2_hit_frac", 0.0), 4),
             "wave_time_waiting_frac": round(d.get("wave_time_waiting_frac", 0.0), 4),
         }
-    roofline = {
-        "kernel": kernel, "bound": bound, "achieved": round(achieved, 3), "peak": round(peak, 3), "unit": unit,
-        "frac": round(frac, 4), "traffic": traffic,
-        "launch_ms": round(launch_ms, 4), "launches": n_launch, "traversals_per_launch": round(cd["trav_rays"] / max(1, trav_n.value)),
-        "share_of_step": round(float(trav_ms.value if trav_dominant else seg_ms.value) / max(1e-9, float(kernel_ms.value)), 4),
+        return view
+
+    # The two kernel classes of a step (HIP event pairs around every launch; a traversal pair spans the wide kernel
+    # and the exact kernel's retry launch behind it). Since the wide traversal they take about the same time on the
+    # headline scene, so the dominant one is whichever is larger in THIS run and the other is reported beside it.
+    trav = kernel_view("wf_traverse_wide_kernel<0,", trav_ms.value, trav_n.value) if trav_n.value > 0 else None
+    seg = kernel_view("wf_segment_kernel<0>", seg_ms.value, seg_n.value)
+    trav_dominant = trav is not None and trav_ms.value >= seg_ms.value
+    dom, other = (trav, seg) if trav_dominant else (seg, trav)
+    trav_s = max(float(trav_ms.value) * 1e-3, 1e-12)
+    if dom["frac"] is None:
+        # no committed PMC passes for this kernel: fall back to the executed flops against the FP32 vector peak
+        x_tflops = xf / trav_s / 1e12 if trav is not None else 0.0
+        dom.update({"bound": "valu", "achieved": round(x_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(x_tflops / VALU_PEAK_TFLOPS, 4)})
+    xtr = max(1, xd["trav_rays"])
+    roofline = dict(dom)
+    roofline.update({
         "timing": "HIP event pairs around every launch on the library's stream, inside the timed region (their cost is in value)",
-        "pmc": pmc_view,
-        # what the kernel executes, counted live on the same samples by its counting twin
-        "executed": {"bytes_per_traversal": round(xb / tr, 1), "flops_per_traversal": round(xf / tr, 1),
-                     "vmem": {"achieved": round(x_gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s requested of L1/L2", "frac": round(x_gbs / L2_PEAK_GBS, 4)},
-                     "valu": {"achieved": round(x_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(x_tflops / VALU_PEAK_TFLOPS, 4)},
-                     "per_traversal": {"node_records": round(cd["x_item_lanes"] / tr, 2), "leaf_visits_with_group_boxes": round(cd["x_half_lanes"] / tr, 2),
-                                       "work_units": round(cd["x_units"] / tr, 2), "triangle_slots_tested": round(8 * cd["x_units"] / tr, 1),
-                                       "descent_lanes_per_iteration": round(cd["x_item_lanes"] / max(1, cd["x_iters"]), 1),
-                                       "units_per_step": round(cd["x_units"] / max(1, cd["x_unit_steps"]), 1)}},
-        # the reference algorithm's own traffic and work on the same rays, which the kernel mostly avoids
+        "other_kernel": other,
+        "traversals_per_launch": round(cd["trav_rays"] / max(1, trav_n.value)),
+        # what the traversal kernel executes, counted live on the same samples by its counting twin
+        "executed": {"bytes_per_traversal": round(xb / xtr, 1), "flops_per_traversal": round(xf / xtr, 1),
+                     "vmem": {"achieved": round(xb / trav_s / 1e9, 1), "peak": L2_PEAK_GBS, "unit": "GB/s requested of L1/L2",
+                              "frac": round(xb / trav_s / 1e9 / L2_PEAK_GBS, 4)},
+                     "valu": {"achieved": round(xf / trav_s / 1e12, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": round(xf / trav_s / 1e12 / VALU_PEAK_TFLOPS, 4)},
+                     "per_traversal": {"wide_node_visits": round(xd["x_item_lanes"] / xtr, 2), "work_units": round(xd["x_units"] / xtr, 2),
+                                       "triangle_slots_tested": round(8 * xd["x_units"] / xtr, 1),
+                                       "stacked_children_dropped_at_the_pop": round(xd["x_wait_lanes"] / xtr, 2),
+                                       "lanes_visiting_per_iteration": round(xd["x_item_lanes"] / max(1, xd["x_iters"]), 1),
+                                       "units_per_step": round(xd["x_units"] / max(1, xd["x_unit_steps"]), 1)},
+                     "rays_retried_by_the_exact_kernel": xd["x_half_lanes"], "of_them_for_a_full_stack": xd["diag3"]},
+        # the reference algorithm's own traffic and work on the same rays, which the kernels mostly avoid
         "logical": {"bytes_per_traversal": round(lb / tr, 1), "flops_per_traversal": round(lf / tr, 1),
-                    "gbs": round(lb / n_launch / launch_s / 1e9, 1) if trav_dominant else 0.0,
-                    "tflops": round(lf / n_launch / launch_s / 1e12, 2) if trav_dominant else 0.0,
+                    "gbs": round(lb / trav_s / 1e9, 1) if trav is not None else 0.0,
+                    "tflops": round(lf / trav_s / 1e12, 2) if trav is not None else 0.0,
                     "per_traversal": {k: round(cd[k] / tr, 3) for k in ("trav_inner", "trav_box", "trav_tri", "trav_leaf")}},
         "segment_kernel": {"launch_ms": round(float(seg_ms.value) / max(1, seg_n.value), 4), "launches": seg_n.value},
         "step_kernel_ms": round(float(kernel_ms.value) / args.steps, 3),
         "note": "bound = the unit with the highest utilisation in the committed PMC passes, rescaled to this run's launch time: "
                 "the vector-memory front end (texture-addresser busy) against VALU issue at 2 cycles per wave64 instruction "
-                "(MI355X_MICROARCH.md). Not HBM: the 21 MB tree is cache-resident (traffic = measured L2-miss side per launch). "
-                "A sensitivity run agrees: one extra L1-hitting load per descent iteration costs 8 %, 20 extra VALU instructions 2 % (DESIGN.md 3.4)",
-    }
+                "(MI355X_MICROARCH.md). Not HBM: the trees are cache-resident and the path state streams at a third of the HBM "
+                "rate (pmc.hbm_side; traffic = measured L2-miss side per launch). Sensitivity of the wide traversal: 24 extra VALU "
+                "instructions per node visit cost 1 %, one extra L1-hitting load per visit 3 % (DESIGN.md 3.4)",
+    })
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------
     cpu = None

@@ -20,8 +20,8 @@
 // Structure (wave-uniform control flow):
 //   * one ray per lane walks wide nodes: one 64-B record = four child boxes in 8 bits relative to their union
 //     + four links (node index | 0x80000000 + group | -1). Children that are nodes are visited nearest first
-//     (sorted by entry distance, the others stacked with their distance, so that a stacked node behind the best
-//     hit is dropped at the pop without a fetch); children that are GROUPS become work units (owner lane, group)
+//     (sorted by entry distance; the others go on the stack as ONE entry per node with the distance of the nearest of
+//     them, so that children behind the best hit are dropped at the pop without a fetch); children that are GROUPS become work units (owner lane, group)
 //     in the wave's list.
 //   * the lane does not wait for its units. Whenever >= DRAIN_MIN units have gathered the wave tests sixteen of
 //     them per step (four lanes per unit, two triangles per lane in packed FP32, the owner's ray by bpermute) and
@@ -37,8 +37,9 @@
 #define WFW_STACK_ENTRY_BYTES 6                                         /* link (4) + entry distance as bf16 (2) */
 #define WFW_SCAP_MAX 12
 
-template <int FLAGS, int OCC, int CHUNK, int TURN_MIN, int DRAIN_MIN>
+template <int FLAGS, int OCC, int CHUNK, int TURN_MIN, int DRAIN_MIN, int KNOB = 0>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index, int scap) {
+	static_assert(CHUNK >= 1 && CHUNK <= 128, "a chunk's queue entries are held two per lane");
 	static_assert(DRAIN_MIN >= 16 && DRAIN_MIN <= 64 && 63 + 256 < WFW_UNIT_CAP, "the unit list must hold one more iteration's appends");
 	extern __shared__ int lds_stack[];
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -59,23 +60,31 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 	// PtxStats.x_*: visit iterations, lanes visiting in them, rays sent to the retry queue, stacked nodes dropped at the
 	// pop, unit steps, units, drains, commit / refill turns
 	uint64_t x_iters = 0, x_item = 0, x_retry = 0, x_drop = 0, x_usteps = 0, x_units = 0, x_drains = 0, x_turns = 0;
+	// counting variant only: constant-rate clock read by lane 0, summed per phase into PtxStats.diag0..2 (turns without their
+	// unit steps, node visits, unit steps); diag3 = rays retried because their stack was full (the others: equal t)
+#define WFW_CLOCK() (((FLAGS & PT_F_STATS) && lane == 0) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
+	uint64_t dg_turn = 0, dg_visit = 0, dg_unit = 0, dg_over = 0;
 
 	WaveFeed feed;
 	feed.exhausted = false;
 	feed.next = feed.hi = 0;
 	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
 
-	enum { IDLE = 0, DESCEND = 1, DONE = 2 };
+	enum { IDLE = 0, DESCEND = 1, DONE = 2, TAKE = 3 };   // TAKE: the loads of a new ray are in flight
 	int state = IDLE;
 	int path = 0, curr = 0, sp = 0, cur_obj_r = -1;
 	bool redo = false;
 	float cur_d = 0.0f, tmin = 0.0f;
 	f3 o = mk3(0.0f), d = mk3(1.0f), inv = mk3(1.0f);
 	int nunits = 0;   // wave-uniform
+	int qa = 0, qb = 0, feed_base = 0;   // queue entries feed_base + lane and feed_base + 64 + lane of the wave's chunk
+	float4 ta0 = make_float4(0, 0, 0, 0), ta1 = ta0;
+	float tw = 0.0f;
 
 	// the wave tests listed units, sixteen per step, newest first; all of them, or while full steps remain
 	auto unit_steps = [&](bool all) {
 		__builtin_amdgcn_wave_barrier();
+		const unsigned long long cu0 = WFW_CLOCK();
 		if (FLAGS & PT_F_STATS) { if (lane == 0 && nunits > 0) x_drains++; }
 		while (nunits >= 16 || (all && nunits > 0)) {
 			const int take = nunits >= 16 ? 16 : nunits;
@@ -120,9 +129,12 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		__builtin_amdgcn_wave_barrier();
 		// owners lower their culling bound to the best t so far (a NaN pattern = no hit yet leaves it)
 		if (state == DESCEND) tmin = __builtin_fminf(tmin, __uint_as_float(reinterpret_cast<const uint32_t*>(keys)[2 * lane + 1]));
+		dg_unit += WFW_CLOCK() - cu0;
 	};
 
 	for (;;) {
+		const unsigned long long ct0 = WFW_CLOCK();
+		const uint64_t du0 = dg_unit;
 		const int n_desc = (int)__popcll(__ballot(state == DESCEND));
 		if (n_desc == 0 || (64 - n_desc >= TURN_MIN && !feed.exhausted)) {
 			// ---- turn: all listed units are tested, finished traversals commit, idle lanes take new rays ----
@@ -150,8 +162,11 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 			}
 			{
 				const int slot = wave_append(&WF_RCNT(wp, wp.bounce, 1 + slot_index), again);
-				if (again) { wp.retry[slot] = path; if (FLAGS & PT_F_STATS) x_retry++; }
+				if (again) { wp.retry[slot] = path; if (FLAGS & PT_F_STATS) { x_retry++; if (redo) dg_over++; } }
 			}
+			// Refill in two halves. Here: the queue entries of the wave's chunk were fetched when the chunk was claimed
+			// (one per lane and half), so a lane picks its entry out of a neighbour's register and ISSUES the loads of its
+			// ray; the loads are taken up after the node visit below, whose own round trip covers theirs.
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				const unsigned long long idle = __ballot(state == IDLE);
 				if (idle == 0ull) break;
@@ -159,30 +174,29 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 					if (feed.exhausted) break;
 					feed_claim(feed, cursor, n, CHUNK);
 					if (feed.exhausted) break;
+					feed_base = feed.next;
+					qa = feed_base + lane < feed.hi ? queue[feed_base + lane] : 0;
+					qb = feed_base + 64 + lane < feed.hi ? queue[feed_base + 64 + lane] : 0;
 				}
 				const int mine = feed.next + (int)__popcll(idle & lt);
+				const int qi = mine - feed_base;
+				const int ea = __shfl(qa, qi & 63, 64), eb = __shfl(qb, qi & 63, 64);
 				if (state == IDLE && mine < feed.hi) {
 					if (FLAGS & PT_F_STATS) n_taken++;
-					path = queue[mine];
-					const float4 a0 = wp.s0[path], a1 = wp.s1[path];
-					cur_obj_r = __float_as_int(wp.s2[path].w);
-					o = mk3(a0.x, a0.y, a0.z);
-					d = mk3(a1.x, a1.y, a1.z);
-					inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-					cur_d = a0.w;
-					tmin = __builtin_huge_valf();
-					curr = root;
-					sp = 0;
-					redo = false;
-					keys[lane] = ~0ull;
-					flags[lane] = 0u;
-					state = DESCEND;
+					path = qi < 64 ? ea : eb;
+					ta0 = wp.s0[path];
+					ta1 = wp.s1[path];
+					tw = wp.s2[path].w;
+					state = TAKE;
 				}
 				feed.next += (int)__popcll(idle);
 			}
-			if (__ballot(state == DESCEND) == 0ull) break;   // queue drained, nothing in flight
+			if (__ballot(state == DESCEND || state == TAKE) == 0ull) break;   // queue drained, nothing in flight
 		}
 
+		const unsigned long long ct1 = WFW_CLOCK();
+		dg_turn += (ct1 - ct0) - (dg_unit - du0);
+		const uint64_t du1 = dg_unit;
 		// ---- one wide node per descending lane ----
 		if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; x_iters++; } if (state == DESCEND) { x_item++; act++; } }
 		uint32_t gh = 0;          // bit k: child k is a group and the ray touches its box
@@ -190,7 +204,18 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		if (state == DESCEND) {
 			const float4* rec = wn + 4 * (size_t)curr;
 			const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3];
-			const float ax = (f0.x - o.x) * inv.x, ay = (f0.y - o.y) * inv.y, az = (f0.z - o.z) * inv.z;
+			float ax = (f0.x - o.x) * inv.x, ay = (f0.y - o.y) * inv.y, az = (f0.z - o.z) * inv.z;
+			if (KNOB == 1) {   // sensitivity probe (A/B builds only): 24 dependent VALU instructions that change nothing
+				asm volatile("v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
+				             "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
+				             "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
+				             "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0" : "+v"(ax));
+			}
+			if (KNOB == 2) {   // sensitivity probe: one more 4-B load from the record (an L1 hit), waited for inside the statement
+				float again;
+				asm volatile("global_load_dword %0, %1, off offset:16\n s_waitcnt vmcnt(0)" : "=v"(again) : "v"(rec) : "memory");
+				asm volatile("" :: "v"(again));
+			}
 			const float sx = f0.w * inv.x, sy = f1.x * inv.y, sz = f1.y * inv.z;
 			const uint32_t w0 = __float_as_uint(f1.z), w1 = __float_as_uint(f1.w), w2 = __float_as_uint(f2.x),
 			               w3 = __float_as_uint(f2.y), w4 = __float_as_uint(f2.z), w5 = __float_as_uint(f2.w);
@@ -221,33 +246,41 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 #define WFW_CX(A, B) { const uint32_t lo_ = A < B ? A : B, hi_ = A < B ? B : A; A = lo_; B = hi_; }
 			WFW_CX(k0, k1) WFW_CX(k2, k3) WFW_CX(k0, k2) WFW_CX(k1, k3) WFW_CX(k1, k2)
 #undef WFW_CX
-			// the link in slot (key & 3): value selects (a lambda over references to r0..r3 made the compiler index them in scratch)
-#define WFW_LINK(KEY) ((((KEY) & 3u) == 3u) ? r3 : ((((KEY) & 3u) == 2u) ? r2 : ((((KEY) & 3u) == 1u) ? r1 : r0)))
+			// children that are nodes sit in slots 0.. with consecutive indices (ptx_scene_upload): link of slot s = r0 + s
 			if (k0 != 0xffffffffu) {
-				curr = WFW_LINK(k0);
-				const int more = (k1 != 0xffffffffu ? 1 : 0) + (k2 != 0xffffffffu ? 1 : 0) + (k3 != 0xffffffffu ? 1 : 0);
-				if (sp + more > scap) {
-					redo = true;          // the stack would overflow: the exact kernel takes this ray
-					state = DONE;
-				} else {
-					// farthest first, so that the nearest is popped first
-					if (k3 != 0xffffffffu) { stack[sp * PT_BLOCK] = WFW_LINK(k3); sdist[sp * PT_BLOCK] = (unsigned short)(k3 >> 16); ++sp; }
-					if (k2 != 0xffffffffu) { stack[sp * PT_BLOCK] = WFW_LINK(k2); sdist[sp * PT_BLOCK] = (unsigned short)(k2 >> 16); ++sp; }
-					if (k1 != 0xffffffffu) { stack[sp * PT_BLOCK] = WFW_LINK(k1); sdist[sp * PT_BLOCK] = (unsigned short)(k1 >> 16); ++sp; }
+				curr = r0 + (int)(k0 & 3u);
+				const uint32_t more = (k1 != 0xffffffffu ? 1u : 0u) + (k2 != 0xffffffffu ? 1u : 0u) + (k3 != 0xffffffffu ? 1u : 0u);
+				if (more != 0u) {
+					if (sp >= scap) {
+						redo = true;          // the stack is full: the exact kernel takes this ray
+						state = DONE;
+					} else {
+						// ONE entry for the node: its inner children sit in slots 0.. with consecutive indices, so the
+						// entry is (index of slot 0) << 8 | the slots still to visit, nearest first, 2 bits each | their
+						// number; beside it the entry distance of the nearest of them, rounded DOWN to bf16
+						stack[sp * PT_BLOCK] = (int)(((uint32_t)r0 << 8) | ((k3 & 3u) << 6) | ((k2 & 3u) << 4) | ((k1 & 3u) << 2) | more);
+						sdist[sp * PT_BLOCK] = (unsigned short)(k1 >> 16);
+						++sp;
+					}
 				}
 			} else {
-				// pop; a stacked node the ray enters beyond the best hit so far is dropped (its distance was rounded
-				// DOWN to bf16, so nothing that could matter is dropped)
+				// pop the nearest child still to visit of the newest entry. An entry whose nearest remaining child the ray
+				// enters beyond the best hit so far is dropped whole (the others are farther; the distance was rounded
+				// down and is kept as a lower bound for them)
 				state = DONE;
 				while (sp > 0) {
-					--sp;
-					const float dn = __uint_as_float((uint32_t)sdist[sp * PT_BLOCK] << 16);
-					if (!(dn > tmin)) { curr = stack[sp * PT_BLOCK]; state = DESCEND; break; }
-					if (FLAGS & PT_F_STATS) x_drop++;
+					const uint32_t e = (uint32_t)stack[(sp - 1) * PT_BLOCK];
+					const float dn = __uint_as_float((uint32_t)sdist[(sp - 1) * PT_BLOCK] << 16);
+					const uint32_t left = e & 3u;
+					if (dn > tmin) { --sp; if (FLAGS & PT_F_STATS) x_drop += left; continue; }
+					curr = (int)((e >> 8) + ((e >> 2) & 3u));
+					if (left == 1u) --sp;
+					else stack[(sp - 1) * PT_BLOCK] = (int)((e & ~0xffu) | (((e >> 4) & 0xfu) << 2) | (left - 1u));
+					state = DESCEND;
+					break;
 				}
 			}
 		}
-#undef WFW_LINK
 		// append the touched groups to the wave's list (ballot + popcount prefix, no atomics)
 #define WFW_APPEND(BIT, REF) { \
 			const bool on_ = (gh & (BIT)) != 0u; \
@@ -257,7 +290,27 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		WFW_APPEND(1u, gref0) WFW_APPEND(2u, gref1) WFW_APPEND(4u, gref2) WFW_APPEND(8u, gref3)
 #undef WFW_APPEND
 		if (nunits >= DRAIN_MIN) unit_steps(false);
+		// second half of the refill: the new rays start
+		if (state == TAKE) {
+			cur_obj_r = __float_as_int(tw);
+			o = mk3(ta0.x, ta0.y, ta0.z);
+			d = mk3(ta1.x, ta1.y, ta1.z);
+			inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+			cur_d = ta0.w;
+			tmin = __builtin_huge_valf();
+			curr = root;
+			sp = 0;
+			redo = false;
+			keys[lane] = ~0ull;
+			flags[lane] = 0u;
+			state = DESCEND;
+		}
+		dg_visit += (WFW_CLOCK() - ct1) - (dg_unit - du1);
 	}
 	stats_flush(wp.stats, TraceCounters{0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
-	if (FLAGS & PT_F_STATS) exec_flush(wp.stats, x_iters, x_item, x_retry, x_drop, x_usteps, x_units, x_drains, x_turns);
+	if (FLAGS & PT_F_STATS) {
+		exec_flush(wp.stats, x_iters, x_item, x_retry, x_drop, x_usteps, x_units, x_drains, x_turns);
+		diag_flush(wp.stats, dg_turn, dg_visit, dg_unit, dg_over);
+	}
+#undef WFW_CLOCK
 }

@@ -59,6 +59,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
+	int wide_cfg, wide_scap;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -123,7 +124,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap;
 	bool force_megakernel;
 };
 
@@ -142,6 +143,9 @@ static Tuning tuning_defaults() {
 	t.trav_blocks_per_cu = clampi(env_int("PTX_TRAV_BLOCKS", 16), 1, 64);
 	// padding of the group boxes (pt_scene.h) relative to the mesh diagonal, in parts per million; read at scene upload
 	t.grp_pad_ppm = clampi(env_int("PTX_GRP_PAD_PPM", PT_GRP_PAD_PPM_DEFAULT), 0, 1000000);
+	// wide traversal (pt_wide.h): A/B configuration of the kernel and the most stack entries a lane may hold
+	t.wide_cfg = env_int("PTX_WIDE_CFG", 0);
+	t.wide_scap = clampi(env_int("PTX_WIDE_SCAP", WFW_SCAP_MAX), 1, 32);
 	return t;
 }
 
@@ -152,6 +156,8 @@ static void tune_defaults(PtxCtx* c) {
 	c->trav_variant = t.trav_variant;
 	c->trav_blocks_per_cu = t.trav_blocks_per_cu;
 	c->grp_pad_ppm = t.grp_pad_ppm;
+	c->wide_cfg = t.wide_cfg;
+	c->wide_scap = t.wide_scap;
 }
 
 extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
@@ -162,6 +168,8 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d.wf_batch : clampi(value, 1, 256);
 	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d.force_megakernel : value != 0;
 	else if (!strcmp(key, "grp_pad_ppm")) ctx->grp_pad_ppm = value < 0 ? d.grp_pad_ppm : clampi(value, 0, 1000000);
+	else if (!strcmp(key, "wide_cfg")) ctx->wide_cfg = value < 0 ? d.wide_cfg : value;
+	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
 	return PTX_OK;
 }
@@ -334,7 +342,7 @@ struct WideBuilder {
 	std::vector<float4>& out;               // 4 float4 per wide node
 	std::vector<float> kd_box;              // per KD node of the object: 6 floats, filled bottom-up
 	int base = 0;                           // first KD node of the object
-	int max_stack = 0;                      // most entries a traversal can hold at once
+	int max_stack = 0;                      // most stack entries a traversal can hold at once (one per node with two or more inner children)
 
 	static float area(const WideItem& it) {
 		const float dx = it.hi[0] - it.lo[0], dy = it.hi[1] - it.lo[1], dz = it.hi[2] - it.lo[2];
@@ -427,8 +435,10 @@ struct WideBuilder {
 			}
 		}
 	}
-	// emits the wide node over `list` (1..4 items) and everything beneath; returns its index
-	int emit(std::vector<WideItem> list, int stack_above) {
+	// Writes wide node `idx` over `list` (0..4 items) and everything beneath. Children that are nodes come FIRST in the
+	// record and get CONSECUTIVE indices (link of slot s = link of slot 0 + s): the traversal stacks one entry per
+	// node, (first child's index, the slots still to visit), so `depth` = stack entries a ray can hold below here.
+	void emit(int idx, std::vector<WideItem> list, int depth) {
 		std::vector<WideItem> ch;
 		for (;;) {
 			int pick = -1;
@@ -443,26 +453,31 @@ struct WideBuilder {
 			list.erase(list.begin() + pick);
 			list.insert(list.end(), ch.begin(), ch.end());
 		}
-		const int idx = (int)(out.size() / 4);
-		out.resize(out.size() + 4, make_float4(0, 0, 0, 0));
+		std::stable_partition(list.begin(), list.end(), [](const WideItem& it) { return !is_group(it); });
+		int inner = 0;
+		for (size_t i = 0; i < list.size(); ++i) if (!is_group(list[i])) ++inner;
+		const int first = (int)(out.size() / 4);
+		out.resize(out.size() + (size_t)inner * 4, make_float4(0, 0, 0, 0));
+		const int below = depth + (inner > 1 ? 1 : 0);
+		if (below > max_stack) max_stack = below;
 		float lo[4][3], hi[4][3];
 		bool used[4] = {false, false, false, false};
 		int32_t ref[4] = {-1, -1, -1, -1};
-		int inner = 0;
-		for (size_t i = 0; i < list.size(); ++i) if (!is_group(list[i])) ++inner;
-		// the traversal follows one inner child and stacks the others
-		const int below = stack_above + (inner > 0 ? inner - 1 : 0);
-		if (below > max_stack) max_stack = below;
 		for (size_t i = 0; i < list.size(); ++i) {
 			used[i] = true;
 			for (int k = 0; k < 3; ++k) { lo[i][k] = list[i].lo[k]; hi[i][k] = list[i].hi[k]; }
 			if (is_group(list[i])) ref[i] = (int32_t)(0x80000000u | (uint32_t)list[i].a);
-			else { children(list[i], ch); ref[i] = emit(ch, below); }
+			else { ref[i] = first + (int)i; children(list[i], ch); emit(first + (int)i, ch, below); }
 		}
 		float4 q[3];
 		quantise_boxes4(lo, hi, used, q);
 		out[(size_t)idx * 4 + 0] = q[0]; out[(size_t)idx * 4 + 1] = q[1]; out[(size_t)idx * 4 + 2] = q[2];
 		out[(size_t)idx * 4 + 3] = make_float4(as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]));
+	}
+	int emit_root(const std::vector<WideItem>& list) {
+		const int idx = (int)(out.size() / 4);
+		out.resize(out.size() + 4, make_float4(0, 0, 0, 0));
+		emit(idx, list, 0);
 		return idx;
 	}
 };
@@ -734,11 +749,11 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 		std::vector<WideItem> top;
 		if (WideBuilder::is_group(root)) top.push_back(root);
 		else if (!WideBuilder::is_empty(root)) wb.children(root, top);
-		wide_root[(size_t)oi] = wb.emit(top, 0);
+		wide_root[(size_t)oi] = wb.emit_root(top);
 		if (wb.max_stack > wide_stack) wide_stack = wb.max_stack;
 	}
 	if (wide.empty()) wide.assign(4, make_float4(0, 0, 0, 0));
-	if (wide.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu wide nodes; the limit is 2^26", wide.size() / 4);
+	if (wide.size() / 4 >= ((size_t)1 << 24)) return fail(PTX_E_LIMIT, "scene has %zu wide nodes; the limit is 2^24", wide.size() / 4);
 	if (grp_boxes.size() / 2 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu triangle groups; the limit is 2^26", grp_boxes.size() / 2);
 	// the traversal kernels address node / leaf-half records with 32-bit byte offsets from the array base
 	if (nodes.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu KD node and leaf-half records; the limit is 2^26", nodes.size() / 4);
@@ -920,9 +935,21 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   12: unified item loop (pt_unified.h): descent and group boxes in one loop, units tested once 16 have gathered
 	//   0 / 14: wide traversal (pt_wide.h) + the exact kernel (leaf mode 9) over its retry queue; 14 counts with its own twin, 0 with the exact kernel
 	//   15: leaf mode 9 alone (the default before the wide traversal)
-	const int scap = scene->dev.wide_stack < WFW_SCAP_MAX ? scene->dev.wide_stack : WFW_SCAP_MAX;
+	const int scap = scene->dev.wide_stack < ctx->wide_scap ? scene->dev.wide_stack : ctx->wide_scap;
 	const size_t wide_lds = (size_t)scap * PT_BLOCK * WFW_STACK_ENTRY_BYTES + WFW_BYTES;
-#define WIDE(F) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, 5, WF_CHUNK, WFW_TURN_MIN, WFW_DRAIN_MIN>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap)
+#define WIDEK(F, O, T, D, ...) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, O, WF_CHUNK, T, D, ##__VA_ARGS__>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap)
+	// <stats, waves/SIMD for the register allocator, -, lanes that must wait before a turn, units that must gather before a drain>
+#define WIDE(F) switch (ctx->wide_cfg) { \
+		case 1: WIDEK(F, 5, 4, WFW_DRAIN_MIN); break; \
+		case 2: WIDEK(F, 5, 16, WFW_DRAIN_MIN); break; \
+		case 3: WIDEK(F, 5, WFW_TURN_MIN, 16); break; \
+		case 4: WIDEK(F, 5, WFW_TURN_MIN, 64); break; \
+		case 5: WIDEK(F, 4, WFW_TURN_MIN, WFW_DRAIN_MIN); break; \
+		case 6: WIDEK(F, 6, WFW_TURN_MIN, WFW_DRAIN_MIN); break; \
+		case 7: WIDEK(F, 5, 12, 48); break; \
+		case 8: WIDEK(F, 5, WFW_TURN_MIN, WFW_DRAIN_MIN, 1); break; \
+		case 9: WIDEK(F, 5, WFW_TURN_MIN, WFW_DRAIN_MIN, 2); break; \
+		default: WIDEK(F, 5, WFW_TURN_MIN, WFW_DRAIN_MIN); break; }
 	const bool uni_fits = lds + WF_UNI_BYTES <= 64 * 1024;
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
@@ -931,6 +958,8 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 		WfParams wr = wp;
 		wr.use_retry = 1;
 		const WfParams& wp = wr;   // the launch macros name `wp`
+		// few rays (bench scene: about a dozen of 40 million): one workgroup per CU; a full persistent grid costs 0.3 ms
+		const size_t tb = (size_t)cus;
 		if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 9);
 		else if (stage_fits) COOP(0, 5, 64, 32, 4);
 		else COOP(0, 4, 64, 32, 3);
@@ -970,6 +999,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 			break;
 	}
 #undef WIDE
+#undef WIDEK
 #undef TRAV
 #undef COOP
 #undef UNI

@@ -1,0 +1,116 @@
+"""The wide traversal (csrc/pt_wide.h, the default since round 2) and its exits to the exact kernel.
+
+The wide kernel walks its own 4-wide tree and returns the minimum t over all triangles; which of two triangles
+with the SAME t wins is the reference's visiting order, which only the exact kernel (leaf mode 9) knows. Rays
+in that situation, and rays whose stack is full, go through the retry queue. These tests force both exits and
+compare with the oracle / the exact kernel bit for bit; the counters of the wide kernel's own counting twin
+(variant 14) prove that the exits were taken. All through the C ABI."""
+import numpy as np
+import pytest
+
+import gpuops
+
+pytestmark = pytest.mark.gpu
+
+
+def _tune(pt, ctx, key, value):
+    pt.check(pt.lib().ptx_ctx_tune(ctx, key, value))
+
+
+def test_equal_t_from_two_blocks_goes_to_the_exact_kernel(pt, orc, ctx, tmp_path):
+    """100 identical triangles form one leaf of four 32-slot blocks: every hit has the same t in all of them, the
+    wide kernel cannot know which the reference tests first, and the exact kernel must decide (the first)."""
+    # ONE mesh: a bumpy floor that makes the builder split, and 100 copies of one triangle above it (equal centroids:
+    # they stay together in a leaf that spans several blocks)
+    g = 12
+    lines = ["mtllib d.mtl", "usemtl white.diff"]
+    for z in range(g + 1):
+        for x in range(g + 1):
+            lines.append(f"v {x - g / 2} {0.05 * ((x * 7 + z * 3) % 5)} {z - g / 2}")
+    vid = lambda x, z: z * (g + 1) + x + 1
+    for z in range(g):
+        for x in range(g):
+            lines.append(f"f {vid(x, z)} {vid(x + 1, z + 1)} {vid(x + 1, z)}")
+            lines.append(f"f {vid(x, z)} {vid(x, z + 1)} {vid(x + 1, z + 1)}")
+    nv = (g + 1) * (g + 1)
+    lines += ["usemtl mirror.spec", "v -3 0.5 -3", "v 3 0.5 -3", "v 0 4 -3"] + [f"f {nv + 1} {nv + 2} {nv + 3}"] * 100
+    (tmp_path / "both.obj").write_text("\n".join(lines) + "\n")
+    (tmp_path / "d.mtl").write_text("newmtl white.diff\nKd 0.8 0.8 0.8\nnewmtl mirror.spec\nKd 0.9 0.9 0.9\nNs 900\nd 0.8\n")
+    (tmp_path / "s.json").write_text(
+        '{"camera": {"pixelWidth": 96, "pixelHeight": 64, "direction": [0,-0.5,-1], "up": [0,1,0], "position": [0,6,12],'
+        ' "screenDist": 1.5, "screenHeight": 2}, "objects": ['
+        '{"type": "sphere", "render": true, "radius": 4, "position": [0, 12, 0], "material": {"type": "lumi", "Kd": [1], "Ke": [6]}},'
+        '{"type": "mesh", "render": true, "src": "%s"}]}' % (tmp_path / "both.obj"))
+    desc, cam = pt.load_scene(str(tmp_path / "s.json"))
+    d0 = desc.contents
+    assert d0.num_nodes > 3 and max(d0.nodes[i].num_tris for i in range(d0.num_nodes)) >= 100
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 0, 4, 6)
+    try:
+        _tune(pt, ctx, b"trav_variant", 14)
+        acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 4, 6, stats=True)
+        d = st_g.as_dict()
+        assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32))
+        assert d["x_half_lanes"] > 50, "no ray went through the retry queue"      # rays retried
+        assert d["diag3"] == 0                                                    # none of them for a full stack
+        _tune(pt, ctx, b"trav_variant", 0)
+        acc_f, _ = gpuops.render(ctx, scene, cam, 0, 4, 6)
+        assert np.array_equal(acc_o.view(np.uint32), acc_f.view(np.uint32))
+    finally:
+        _tune(pt, ctx, b"trav_variant", -1)
+    # ray by ray through the production kernel: the hits name the FIRST of the identical triangles
+    o, dd = orc.generate_rays(cam, -1, 0)
+    ho, hq = orc.trace(desc, o, dd, 1), gpuops.trace_queued(ctx, scene, o, dd, 1)
+    first_copy = 2 * g * g
+    on_copies = (ho["hit"] == 1) & (ho["prim"].astype(np.int64) >= first_copy) & (ho["prim"] != 0xFFFFFFFF)
+    assert on_copies.sum() > 50 and set(ho["prim"][on_copies]) == {first_copy}
+    for k in ("object", "prim", "t_bits", "bary"):
+        assert np.array_equal(ho[k], hq[k]), k
+
+
+@pytest.mark.parametrize("scap", [1, 2, 3])
+def test_full_stack_goes_to_the_exact_kernel(pt, orc, ctx, scap):
+    """With room for only `scap` stack entries most rays of the car give up and are traced again by the exact
+    kernel: the image must not change by a bit, and the counters must show the exit."""
+    desc, cam = pt.load_scene("lamborghini", width=160, height=90, textures=1)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 0, 2, 5)
+    try:
+        _tune(pt, ctx, b"wide_scap", scap)
+        _tune(pt, ctx, b"trav_variant", 14)
+        acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 2, 5, stats=True)
+        d = st_g.as_dict()
+        assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32))
+        assert d["diag3"] > 100 and d["x_half_lanes"] >= d["diag3"], (d["diag3"], d["x_half_lanes"])
+        assert d["rays"] == st_o.rays and d["trav_rays"] == st_o.trav_rays
+        _tune(pt, ctx, b"trav_variant", 0)
+        acc_f, _ = gpuops.render(ctx, scene, cam, 0, 2, 5)
+        assert np.array_equal(acc_o.view(np.uint32), acc_f.view(np.uint32))
+    finally:
+        _tune(pt, ctx, b"wide_scap", -1)
+        _tune(pt, ctx, b"trav_variant", -1)
+
+
+def test_wide_and_exact_kernels_agree_on_every_scene(pt, ctx):
+    """Variant 0 (wide + retry), 14 (the same with its own counting twin) and 15 (the exact kernel alone) give the
+    same accumulation buffer on every shipped scene with a multi-node mesh; the default stack never overflows on
+    the car."""
+    for name in ("lamborghini", "teapot"):
+        desc, cam = pt.load_scene(name, width=192, height=108, textures=1)
+        scene = pt.host().pth_scene_device()
+        gpuops.render_init(ctx, cam)
+        try:
+            _tune(pt, ctx, b"trav_variant", 15)
+            ref, _ = gpuops.render(ctx, scene, cam, 5, 3, 11)
+            for variant, stats in ((0, False), (0, True), (14, False), (14, True)):
+                _tune(pt, ctx, b"trav_variant", variant)
+                acc, st = gpuops.render(ctx, scene, cam, 5, 3, 11, stats=stats)
+                assert np.array_equal(ref.view(np.uint32), acc.view(np.uint32)), (name, variant, stats)
+                if variant == 14 and stats:
+                    d = st.as_dict()
+                    assert d["x_item_lanes"] > 0 and d["x_units"] > 0
+                    assert d["diag3"] == 0, f"{name}: {d['diag3']} rays overflowed the default stack"
+        finally:
+            _tune(pt, ctx, b"trav_variant", -1)

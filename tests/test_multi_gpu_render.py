@@ -9,6 +9,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch   # before the first HIP call of libptx_hip.so: torch brings its own HIP runtime, and initialised second it finds no GPU
 
 import gpuops
 
