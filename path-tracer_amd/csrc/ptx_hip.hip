@@ -927,7 +927,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   2 = mode 1 with two steps' loads in flight.
 	// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
 	// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
-	//   0: 3830 (leaf mode 9, 128-sample passes; the other figures are 64-sample passes of round 1)   13: leaf mode 6 (3690)   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
+	//   0: 6750 (wide traversal, pt_wide.h, 128-sample passes; the other figures are 64-sample passes of round 1)   15: leaf mode 9 alone (3830)   13: leaf mode 6 (3690)   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
 	//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
 	//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
 	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3090)   11: mode 5 (3150)
