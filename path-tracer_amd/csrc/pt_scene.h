@@ -59,6 +59,14 @@
 //              box g's bytes are 6g .. 6g+5; an unused group slot is (255, 255, 255, 0, 0, 0): never touched.
 //              The decoded box contains the fp32 one (outward rounding, at most 1/255 of the block's extent per
 //              side), so the filter stays conservative; three 16-B loads per leaf instead of eight.
+//   cheap_pairs  for the SINGLE-LEAF meshes (sky cube, floor: intersected inline by the segment kernel, every ray against
+//              every such mesh): per pair of consecutive triangles (2j, 2j + 1) of the run the box of its vertices,
+//              (lo.xyz, -) (hi.xyz, -), padded like a group box. The root leaf's node record carries the mesh's first
+//              pair in q0.y (int). A lane tests the boxes (wave-uniform data) and then only the pairs it touches,
+//              in run order: a ray inside the sky cube tests one face instead of twelve triangles.
+//   wide_nodes the 4-wide tree over the groups that the wide traversal walks (pt_wide.h): 64 B per node = the four child
+//              boxes in the grp_qbox form (f0..f2) + int4 links (>= 0 node, 0x80000000 | group, -1 none); children
+//              that are nodes come first and have consecutive indices. wide_root[object] = its root (-1: none).
 //   tri_shade  4 x float4 per triangle (64 B), same order, touched once per mesh hit:
 //                s0 = (na.xyz, ta.x) s1 = (nb.xyz, ta.y) s2 = (nc.xyz, tb.x)
 //                s3 = (tb.y, tc.x, tc.y, int material_global_idx)
@@ -102,6 +110,7 @@ struct DevScene {
 	const float4* tri_grp;
 	const float4* grp_box;
 	const float4* grp_qbox; // 3 float4 (48 B) per 32-triangle block: the block's four group boxes quantised to 8 bits (below)
+	const float4* cheap_pairs; // 2 float4 per pair of consecutive triangles of a single-leaf mesh: its padded box (below)
 	const float4* wide_nodes; // 4 float4 (64 B) per node of the 4-wide tree over the groups (below)
 	const int32_t* wide_root; // per object: its wide root node, -1 if it has none
 	const float4* tri_shade;

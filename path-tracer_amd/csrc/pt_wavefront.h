@@ -194,8 +194,63 @@ PT_DEV bool leaf_only_mesh(const DevScene& sc, const DevObject& ob, const Ray& r
 	return intersects;
 }
 
+// The same mesh through its PAIR boxes (pt_scene.h, cheap_pairs): every lane first tests the boxes of all pairs of
+// consecutive triangles (wave-uniform data: scalar loads, one slab test each) and then only the pairs its ray touches
+// (its own loads from tri_geom), in run order with strict '<' - what the serial loop above keeps, because a pair
+// whose padded box the ray misses holds no hit (the argument of the group boxes). A ray inside the
+// sky cube tests one face instead of twelve triangles; the loop below runs once for most waves.
+template <int FLAGS>
+PT_DEV bool leaf_only_mesh_pairs(const DevScene& sc, const DevObject& ob, const Ray& ray, float& tmin, int& best_tri,
+                                 float& bu, float& bv, TraceCounters& cnt) {
+	const float4 q3 = sc.nodes[4 * ob.root_node + 3];
+	const float4 q0 = sc.nodes[4 * ob.root_node + 0];
+	const int first = __builtin_amdgcn_readfirstlane(__float_as_int(q3.z));
+	const int count = __builtin_amdgcn_readfirstlane(__float_as_int(q3.w));
+	const int pair_base = __builtin_amdgcn_readfirstlane(__float_as_int(q0.y));
+	if (FLAGS & PT_F_STATS) { cnt.n_leaf++; cnt.n_tri += (uint32_t)count; }   // the reference's count: every triangle of the leaf
+	const int npairs = (count + 1) >> 1;
+	// slab test as fma(plane, inv, -o * inv); a NaN (0 * inf, inf - inf) drops out of min / max: that axis does not constrain
+	const float nx = -ray.o.x * ray.inv.x, ny = -ray.o.y * ray.inv.y, nz = -ray.o.z * ray.inv.z;
+	bool intersects = false;
+	for (int base = 0; base < npairs; base += 32) {
+		const int nb = npairs - base < 32 ? npairs - base : 32;
+		uint32_t touched = 0;
+		for (int j = 0; j < nb; ++j) {
+			const float4* pr = sc.cheap_pairs + 2 * (size_t)(pair_base + base + j);
+			const float4 lo = pr[0], hi = pr[1];
+			const float ax = __builtin_fmaf(lo.x, ray.inv.x, nx), bx = __builtin_fmaf(hi.x, ray.inv.x, nx);
+			const float ay = __builtin_fmaf(lo.y, ray.inv.y, ny), by = __builtin_fmaf(hi.y, ray.inv.y, ny);
+			const float az = __builtin_fmaf(lo.z, ray.inv.z, nz), bz = __builtin_fmaf(hi.z, ray.inv.z, nz);
+			const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+			const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+			if (!(tn > tf) && !(tf < 0.0f)) touched |= 1u << j;
+		}
+		while (__ballot(touched != 0u) != 0ull) {
+			if (touched != 0u) {
+				const int j = (int)__ffs((int)touched) - 1;
+				touched &= touched - 1u;
+				const int t0 = first + 2 * (base + j);
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {   // the slot behind an odd run's last triangle is a zero record: never hit
+					const float4 g0 = sc.tri_geom[3 * (t0 + h) + 0], g1 = sc.tri_geom[3 * (t0 + h) + 1], g2 = sc.tri_geom[3 * (t0 + h) + 2];
+					float t, u, v;
+					if (tri_test_flat(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
+						intersects = true;
+						if (t < tmin) { tmin = t; best_tri = t0 + h; bu = u; bv = v; }
+					}
+				}
+			}
+		}
+	}
+	return intersects;
+}
+
+#ifndef WF_CHEAP_PAIRS
+#define WF_CHEAP_PAIRS 1   // single-leaf meshes through their pair records (0: every triangle, as round 1)
+#endif
 #ifndef WF_SEG_OCC
-#define WF_SEG_OCC 5   // 96 registers, 11 spilled values; at 6 waves/SIMD (80 registers) the compacted-state version spills 35: 7.40 vs 7.14 ms
+#define WF_SEG_OCC 4   // r2, with the pair filter of the single-leaf meshes: 128 registers, no spills: 6.61 ms per launch; at 5 waves/SIMD
+                       // (96 registers, 33 spilled values) 7.29 ms. Without the filter: 7.13 ms at 5 (11 spilled), 7.25 at 4.
 #endif
 template <int FLAGS>
 __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevScene sc, DevCamera cam, WfParams wp) {
@@ -392,7 +447,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 				} else if (enter) {
 					float tmin = __builtin_huge_valf(), bu = 0.0f, bv = 0.0f;
 					int tri = -1;
-					bool hit = leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
+					bool hit = WF_CHEAP_PAIRS ? leaf_only_mesh_pairs<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt) : leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
 					if (hit && tri >= 0) {
 						const f3 p = ray.o + tmin * ray.d;
 						const float d = length3(p - ray.o);

@@ -507,6 +507,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	nodes.reserve((size_t)d->num_nodes * 4);
 	std::vector<float4> pairs;   // tri_pair blocks (pt_scene.h)
 	std::vector<float4> grp_tris, grp_boxes;   // tri_grp / grp_box (pt_scene.h)
+	std::vector<float4> cheap_pairs;           // pair records of the single-leaf meshes (pt_scene.h)
 	geom.reserve((size_t)d->num_leaf_tris * 3);
 	shade.reserve((size_t)d->num_leaf_tris * 4);
 	int scene_max_depth = 0;
@@ -618,6 +619,28 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 					}
 				}
 				rec[0] = make_float4(as_float(block_first), 0.0f, 0.0f, 0.0f);
+				if (ni == 0) {
+					// a single-leaf mesh is intersected inline by the segment kernel: a padded box for every PAIR of consecutive
+					// triangles of its run (pt_scene.h, cheap_pairs), so that a lane tests only the pairs whose box its ray touches
+					const int pair_base = (int)(cheap_pairs.size() / 2);
+					const int npairs = (nd.num_tris + 1) / 2;
+					for (int j = 0; j < npairs; ++j) {
+						float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+						for (int h = 0; h < 2 && 2 * j + h < nd.num_tris; ++h) {
+							const PtxTriangle& t = d->triangles[o.first_triangle + d->leaf_tris[o.first_leaf_tri + nd.first_tri + 2 * j + h]];
+							for (int c = 0; c < 3; ++c) {
+								const float v[3] = {t.a[c], t.a[c] + t.e1[c], t.a[c] + t.e2[c]};
+								for (int z = 0; z < 3; ++z) {
+									if (v[z] - grp_pad < lo[c]) lo[c] = v[z] - grp_pad;
+									if (v[z] + grp_pad > hi[c]) hi[c] = v[z] + grp_pad;
+								}
+							}
+						}
+						cheap_pairs.push_back(make_float4(lo[0], lo[1], lo[2], 0.0f));
+						cheap_pairs.push_back(make_float4(hi[0], hi[1], hi[2], 0.0f));
+					}
+					rec[0].y = as_float(pair_base);
+				}
 				// and as boxed groups of eight, sorted along the longest axis of the leaf's box (pt_scene.h)
 				{
 					const float inf = __builtin_huge_valf();
@@ -792,6 +815,8 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	UP(grp_tris, tri_grp)
 	UP(grp_boxes, grp_box)
 	UP(qboxes, grp_qbox)
+	if (cheap_pairs.empty()) cheap_pairs.assign(2, make_float4(0, 0, 0, 0));
+	UP(cheap_pairs, cheap_pairs)
 	UP(wide, wide_nodes)
 	UP(wide_root, wide_root)
 	UP(shade, tri_shade)
