@@ -59,7 +59,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
-	int wide_cfg, wide_scap;
+	int wide_cfg, wide_scap, grp_mode;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -124,7 +124,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode;
 	bool force_megakernel;
 };
 
@@ -144,6 +144,7 @@ static Tuning tuning_defaults() {
 	// padding of the group boxes (pt_scene.h) relative to the mesh diagonal, in parts per million; read at scene upload
 	t.grp_pad_ppm = clampi(env_int("PTX_GRP_PAD_PPM", PT_GRP_PAD_PPM_DEFAULT), 0, 1000000);
 	// wide traversal (pt_wide.h): A/B configuration of the kernel and the most stack entries a lane may hold
+	t.grp_mode = clampi(env_int("PTX_GRP_MODE", 1), 0, 1);   // how a leaf's triangles are cut into groups of eight; read at scene upload
 	t.wide_cfg = env_int("PTX_WIDE_CFG", 0);
 	t.wide_scap = clampi(env_int("PTX_WIDE_SCAP", WFW_SCAP_MAX), 1, 32);
 	return t;
@@ -157,6 +158,7 @@ static void tune_defaults(PtxCtx* c) {
 	c->trav_blocks_per_cu = t.trav_blocks_per_cu;
 	c->grp_pad_ppm = t.grp_pad_ppm;
 	c->wide_cfg = t.wide_cfg;
+	c->grp_mode = t.grp_mode;
 	c->wide_scap = t.wide_scap;
 }
 
@@ -168,6 +170,7 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d.wf_batch : clampi(value, 1, 256);
 	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d.force_megakernel : value != 0;
 	else if (!strcmp(key, "grp_pad_ppm")) ctx->grp_pad_ppm = value < 0 ? d.grp_pad_ppm : clampi(value, 0, 1000000);
+	else if (!strcmp(key, "grp_mode")) ctx->grp_mode = value < 0 ? d.grp_mode : clampi(value, 0, 1);
 	else if (!strcmp(key, "wide_cfg")) ctx->wide_cfg = value < 0 ? d.wide_cfg : value;
 	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
@@ -650,14 +653,49 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 						grp_boxes[(size_t)(block_first * 4 + g) * 2] = make_float4(inf, inf, inf, 0.0f);
 						grp_boxes[(size_t)(block_first * 4 + g) * 2 + 1] = make_float4(-inf, -inf, -inf, 0.0f);
 					}
-					int axis = 0;
-					for (int k = 1; k < 3; ++k) if (nd.bmax[k] - nd.bmin[k] > nd.bmax[axis] - nd.bmin[axis]) axis = k;
+					// Order of the run's triangles in the group arrays; groups are consecutive eights of it.
+					//   grp_mode 0: sorted along the longest axis of the leaf's box (strips)
+					//   grp_mode 1: recursive bisection - the (sub)set is sorted by centroid along the longest axis of its
+					//               centroid box and cut at a multiple of eight near its middle: squarer groups, smaller boxes
 					std::vector<std::pair<double, int> > order((size_t)nd.num_tris);
-					for (int k = 0; k < nd.num_tris; ++k) {
-						const PtxTriangle& t = d->triangles[o.first_triangle + d->leaf_tris[o.first_leaf_tri + nd.first_tri + k]];
-						order[(size_t)k] = std::make_pair(3.0 * (double)t.a[axis] + (double)t.e1[axis] + (double)t.e2[axis], k);
+					{
+						std::vector<double> cen((size_t)nd.num_tris * 3);
+						for (int k = 0; k < nd.num_tris; ++k) {
+							const PtxTriangle& t = d->triangles[o.first_triangle + d->leaf_tris[o.first_leaf_tri + nd.first_tri + k]];
+							for (int c = 0; c < 3; ++c) cen[(size_t)k * 3 + c] = 3.0 * (double)t.a[c] + (double)t.e1[c] + (double)t.e2[c];
+							order[(size_t)k] = std::make_pair(0.0, k);
+						}
+						int axis0 = 0;
+						for (int k = 1; k < 3; ++k) if (nd.bmax[k] - nd.bmin[k] > nd.bmax[axis0] - nd.bmin[axis0]) axis0 = k;
+						std::vector<std::pair<int, int> > parts;   // [begin, end) ranges still to order
+						parts.push_back(std::make_pair(0, nd.num_tris));
+						while (!parts.empty()) {
+							const int b = parts.back().first, e = parts.back().second;
+							parts.pop_back();
+							if (e - b <= 1) continue;
+							int axis = axis0;
+							if (ctx->grp_mode == 1) {
+								double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+								for (int i = b; i < e; ++i)
+									for (int c = 0; c < 3; ++c) {
+										const double v = cen[(size_t)order[(size_t)i].second * 3 + c];
+										if (v < lo[c]) lo[c] = v;
+										if (v > hi[c]) hi[c] = v;
+									}
+								axis = 0;
+								for (int c = 1; c < 3; ++c) if (hi[c] - lo[c] > hi[axis] - lo[axis]) axis = c;
+							}
+							for (int i = b; i < e; ++i) order[(size_t)i].first = cen[(size_t)order[(size_t)i].second * 3 + axis];
+							// equal keys keep run order (the pairs compare by key, then by run index)
+							std::sort(order.begin() + b, order.begin() + e);
+							if (ctx->grp_mode != 1) continue;
+							const int groups = (e - b + 7) / 8;
+							if (groups <= 1) continue;
+							const int mid = b + 8 * ((groups + 1) / 2);   // b is a multiple of eight, so every cut is one
+							parts.push_back(std::make_pair(b, mid));
+							parts.push_back(std::make_pair(mid, e));
+						}
 					}
-					std::stable_sort(order.begin(), order.end());   // equal keys keep run order
 					for (int j = 0; j < nd.num_tris; ++j) {
 						const int k = order[(size_t)j].second;
 						const PtxTriangle& t = d->triangles[o.first_triangle + d->leaf_tris[o.first_leaf_tri + nd.first_tri + k]];
