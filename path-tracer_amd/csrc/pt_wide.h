@@ -28,6 +28,7 @@
 //     merges the hits into the owners' keys with LDS atomic minima; the owners then lower their culling bound.
 //   * once TURN_MIN lanes have finished, the remaining units are tested, finished lanes commit (closest object by
 //     distance, as the reference's loop over the objects: src/intersect.cuh:328-346) and idle lanes take new rays.
+// Default configuration <6 waves/SIMD, chunks of 128, turn at 16 waiting lanes, drain at 32 units>: 80 registers.
 #pragma once
 #include "pt_wavefront.h"
 
@@ -35,7 +36,7 @@
 #define WFW_WAVE_BYTES (64 * 8 + 64 * 8 + 64 * 4 + WFW_UNIT_CAP * 4)   /* keys, (u, v), flags, units */
 #define WFW_BYTES ((PT_BLOCK / 64) * WFW_WAVE_BYTES)
 #define WFW_STACK_ENTRY_BYTES 6                                         /* link (4) + entry distance as bf16 (2) */
-#define WFW_SCAP_MAX 12
+#define WFW_SCAP_MAX 10   /* 10 x 6 B x 256 lanes + the waves' areas = 25.6 KB per workgroup: six workgroups per CU */
 
 template <int FLAGS, int OCC, int CHUNK, int TURN_MIN, int DRAIN_MIN, int KNOB = 0>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index, int scap) {
@@ -164,9 +165,10 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 				const int slot = wave_append(&WF_RCNT(wp, wp.bounce, 1 + slot_index), again);
 				if (again) { wp.retry[slot] = path; if (FLAGS & PT_F_STATS) { x_retry++; if (redo) dg_over++; } }
 			}
-			// Refill in two halves. Here: the queue entries of the wave's chunk were fetched when the chunk was claimed
-			// (one per lane and half), so a lane picks its entry out of a neighbour's register and ISSUES the loads of its
-			// ray; the loads are taken up after the node visit below, whose own round trip covers theirs.
+			// Refill. (A/B configuration KNOB 4 splits it in two halves: the queue entries of the wave's chunk are fetched when
+			// the chunk is claimed, a lane picks its entry out of a neighbour's register and only ISSUES the loads of its ray,
+			// which are taken up after the node visit below. Measured: no gain at 5 waves/SIMD, and its 11 extra registers cost
+			// the sixth wave, which is worth 4 %.)
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				const unsigned long long idle = __ballot(state == IDLE);
 				if (idle == 0ull) break;
@@ -175,19 +177,38 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 					feed_claim(feed, cursor, n, CHUNK);
 					if (feed.exhausted) break;
 					feed_base = feed.next;
-					qa = feed_base + lane < feed.hi ? queue[feed_base + lane] : 0;
-					qb = feed_base + 64 + lane < feed.hi ? queue[feed_base + 64 + lane] : 0;
+					if (KNOB == 4) {
+						qa = feed_base + lane < feed.hi ? queue[feed_base + lane] : 0;
+						qb = feed_base + 64 + lane < feed.hi ? queue[feed_base + 64 + lane] : 0;
+					}
 				}
 				const int mine = feed.next + (int)__popcll(idle & lt);
 				const int qi = mine - feed_base;
-				const int ea = __shfl(qa, qi & 63, 64), eb = __shfl(qb, qi & 63, 64);
+				const int ea = KNOB != 4 ? 0 : __shfl(qa, qi & 63, 64), eb = KNOB != 4 ? 0 : __shfl(qb, qi & 63, 64);
 				if (state == IDLE && mine < feed.hi) {
 					if (FLAGS & PT_F_STATS) n_taken++;
-					path = qi < 64 ? ea : eb;
-					ta0 = wp.s0[path];
-					ta1 = wp.s1[path];
-					tw = wp.s2[path].w;
-					state = TAKE;
+					if (KNOB != 4) {   // the whole refill here; KNOB 4 (A/B) splits it: see below
+						path = queue[mine];
+						const float4 a0 = wp.s0[path], a1 = wp.s1[path];
+						cur_obj_r = __float_as_int(wp.s2[path].w);
+						o = mk3(a0.x, a0.y, a0.z);
+						d = mk3(a1.x, a1.y, a1.z);
+						inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+						cur_d = a0.w;
+						tmin = __builtin_huge_valf();
+						curr = root;
+						sp = 0;
+						redo = false;
+						keys[lane] = ~0ull;
+						flags[lane] = 0u;
+						state = DESCEND;
+					} else {
+						path = qi < 64 ? ea : eb;
+						ta0 = wp.s0[path];
+						ta1 = wp.s1[path];
+						tw = wp.s2[path].w;
+						state = TAKE;
+					}
 				}
 				feed.next += (int)__popcll(idle);
 			}

@@ -114,7 +114,7 @@ static int env_int(const char* name, int dflt) {
 #define WF_CHUNK 128
 #endif
 #ifndef WFW_TURN_MIN
-#define WFW_TURN_MIN 8
+#define WFW_TURN_MIN 16
 #endif
 #ifndef WFW_DRAIN_MIN
 #define WFW_DRAIN_MIN 32
@@ -1003,16 +1003,15 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 #define WIDEK(F, O, T, D, ...) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, O, WF_CHUNK, T, D, ##__VA_ARGS__>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap)
 	// <stats, waves/SIMD for the register allocator, -, lanes that must wait before a turn, units that must gather before a drain>
 #define WIDE(F) switch (ctx->wide_cfg) { \
-		case 1: WIDEK(F, 5, 4, WFW_DRAIN_MIN); break; \
-		case 2: WIDEK(F, 5, 16, WFW_DRAIN_MIN); break; \
-		case 3: WIDEK(F, 5, WFW_TURN_MIN, 16); break; \
-		case 4: WIDEK(F, 5, WFW_TURN_MIN, 64); break; \
-		case 5: WIDEK(F, 4, WFW_TURN_MIN, WFW_DRAIN_MIN); break; \
-		case 6: WIDEK(F, 6, WFW_TURN_MIN, WFW_DRAIN_MIN); break; \
-		case 7: WIDEK(F, 5, 12, 48); break; \
-		case 8: WIDEK(F, 5, WFW_TURN_MIN, WFW_DRAIN_MIN, 1); break; \
-		case 9: WIDEK(F, 5, WFW_TURN_MIN, WFW_DRAIN_MIN, 2); break; \
-		default: WIDEK(F, 5, WFW_TURN_MIN, WFW_DRAIN_MIN); break; }
+		case 1: WIDEK(F, 5, 8, 32, 4); break;    /* the first default: 5 waves, turn at 8, split refill */ \
+		case 2: WIDEK(F, 5, 8, 32); break; \
+		case 3: WIDEK(F, 6, 8, 32); break; \
+		case 4: WIDEK(F, 6, 24, 32); break; \
+		case 5: WIDEK(F, 6, 16, 48); break; \
+		case 6: WIDEK(F, 6, 16, 16); break; \
+		case 8: WIDEK(F, 6, WFW_TURN_MIN, WFW_DRAIN_MIN, 1); break;   /* sensitivity probe: + 24 VALU instructions per visit */ \
+		case 9: WIDEK(F, 6, WFW_TURN_MIN, WFW_DRAIN_MIN, 2); break;   /* sensitivity probe: + 1 load per visit */ \
+		default: WIDEK(F, 6, WFW_TURN_MIN, WFW_DRAIN_MIN); break; }
 	const bool uni_fits = lds + WF_UNI_BYTES <= 64 * 1024;
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
