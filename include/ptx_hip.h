@@ -154,12 +154,19 @@ typedef struct PtxStats {
 	 *   x_half_lanes  cooperative kernel: lanes that fetched their leaf's four group boxes (128 B); unified: leaf-half records
 	 *   x_wait_lanes  unified kernel: lanes waiting for their units, summed over iterations
 	 *   x_unit_steps  steps of the unit phase (16 groups of eight triangles each), x_units the groups tested in them
-	 *   x_unit_phases rounds with a leaf phase (unified: unit phases), x_turns commit / refill turns */
+	 *   x_unit_phases rounds with a leaf phase (unified: unit phases), x_turns commit / refill turns
+	 * wide traversal (pt_wide.h, variant 14): x_iters = visit iterations, x_item_lanes = wide-node visits, x_half_lanes =
+	 *   rays handed to the exact kernel (diag3 of them for a full stack), x_wait_lanes = stacked children dropped at the pop,
+	 *   x_unit_steps / x_units as above, x_unit_phases = drains; diag0..2 = clock ticks in turns / node visits / unit steps */
 	uint64_t x_iters, x_item_lanes, x_half_lanes, x_wait_lanes, x_unit_steps, x_units, x_unit_phases, x_turns;
 	/* shading divergence in the segment kernel, counting variant only (the material-sorting question):
 	 * waves in which at least one lane shades a hit, the lanes that do, the BSDF branches (diffuse / specular /
 	 * transparent) those waves execute summed over waves, and lanes per material type 0..3 */
 	uint64_t sh_waves, sh_lanes, sh_branches, sh_type_lanes[4];
+	/* segment kernel, counting variant only: ticks of the shader clock read by lane 0 of every wave, summed per phase:
+	 * [0] generate / resolve + shade + compact, [1] waiting at the workgroup barriers, [2] intersection of the cheap
+	 * objects + state write, [3] queue appends (tools/segment_clock.py prints the shares) */
+	uint64_t seg_clk[4];
 } PtxStats;
 
 /* BSDF known-answer entry (parity for surfaces.cuh). */

@@ -81,7 +81,8 @@ class PtxStats(C.Structure):
                                           "diag0", "diag1", "diag2", "diag3",
                                           "x_iters", "x_item_lanes", "x_half_lanes", "x_wait_lanes", "x_unit_steps", "x_units",
                                           "x_unit_phases", "x_turns", "sh_waves", "sh_lanes", "sh_branches",
-                                          "sh_type0", "sh_type1", "sh_type2", "sh_type3")]
+                                          "sh_type0", "sh_type1", "sh_type2", "sh_type3",
+                                          "seg_clk0", "seg_clk1", "seg_clk2", "seg_clk3")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

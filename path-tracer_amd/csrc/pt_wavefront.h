@@ -262,6 +262,9 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
 	uint64_t n_rays = 0, n_paths = 0, c_hm = 0, c_hs = 0, c_ht = 0;
 	uint64_t sh_waves = 0, sh_lanes = 0, sh_branches = 0, sh_t[4] = {0, 0, 0, 0};
+	// counting variant only: shader clock per phase (PtxStats.seg_clk)
+#define WFS_CLOCK() (((FLAGS & PT_F_STATS) && (threadIdx.x & 63) == 0) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
+	uint64_t sc0 = 0, sc1 = 0, sc2 = 0, sc3 = 0;
 
 	// A workgroup takes WF_ROUNDS x 256 paths per iteration and works in two phases:
 	//   1. generate / shade: one path per lane; the rays that go on are COMPACTED into LDS
@@ -284,6 +287,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 	__syncthreads();
 
 	for (int blk0 = (int)blockIdx.x * CAP; blk0 < n_in; blk0 += (int)gridDim.x * CAP) {
+	const unsigned long long k0 = WFS_CLOCK();
 	// ---- phase 1: generate / shade, compact the survivors ---------------------------------------------
 	for (int round = 0; round < WF_ROUNDS; ++round) {
 		const int i = blk0 + round * PT_BLOCK + tid;
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 			}
 		}
 	} // rounds
+		const unsigned long long k1 = WFS_CLOCK();
 		__syncthreads();
 		const int n_live = sh_n;
 		const int n_chunks = (n_live + PT_BLOCK - 1) / PT_BLOCK;
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 		if (tid == 0) sh_base[0] = n_live ? atomicAdd(&WF_CNT(wp, bounce, 0), n_live) : 0;
 		__syncthreads();
 		const int base0 = sh_base[0];
+		const unsigned long long k2 = WFS_CLOCK();
 
 	// ---- phase 2: intersect the new segments with the cheap objects, enqueue them for the expensive ones ----
 	for (int chunk = 0; chunk < n_chunks; ++chunk) {
@@ -469,7 +475,9 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 			if (lane == 0) sh_cnt[L][chunk * (PT_BLOCK / 64) + wave] = (int)__popcll(m);
 		}
 	} // chunks
+		const unsigned long long k3 = WFS_CLOCK();
 		__syncthreads();
+		const unsigned long long k4 = WFS_CLOCK();
 		if (tid >= 1 && tid < nlists) {   // list 0 (the survivors) was reserved before phase 2
 			int total = 0;
 			for (int j = 0; j < n_chunks * (PT_BLOCK / 64); ++j) {
@@ -494,17 +502,20 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 			}
 		}
 		__syncthreads();
+		const unsigned long long k5 = WFS_CLOCK();
+		sc0 += k1 - k0; sc1 += (k2 - k1) + (k4 - k3); sc2 += k3 - k2; sc3 += k5 - k4;
 	}
 	stats_flush(wp.stats, cnt, n_rays, n_paths, c_hm, c_hs, c_ht, 0, 0, (FLAGS & PT_F_STATS) != 0);
 	if (FLAGS & PT_F_STATS) {
-		uint64_t x[7] = {sh_waves, sh_lanes, sh_branches, sh_t[0], sh_t[1], sh_t[2], sh_t[3]};
+		uint64_t x[11] = {sh_waves, sh_lanes, sh_branches, sh_t[0], sh_t[1], sh_t[2], sh_t[3], sc0, sc1, sc2, sc3};   // seg_clk follows sh_type_lanes
 		unsigned long long* dst = (unsigned long long*)&wp.stats->sh_waves;
 #pragma unroll
-		for (int k = 0; k < 7; ++k) {
+		for (int k = 0; k < 11; ++k) {
 			const uint64_t v = wave_sum_u64(x[k]);
 			if (lane == 0 && v) atomicAdd(dst + k, (unsigned long long)v);
 		}
 	}
+#undef WFS_CLOCK
 }
 
 // KD traversal of the rays queued for one multi-node mesh; merges into the path's closest-hit record.

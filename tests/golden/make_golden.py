@@ -174,7 +174,7 @@ def make_oracle_vectors():
         acc, st = orc.render(desc, cam, 0, 8, 42)
         vec[f"render_{scene}"] = acc.view(np.uint32)
         meta["render"].append({"scene": scene, "width": 64, "height": 48, "spp": 8, "seed": 42, "textures": 1 if scene == "sky_map" else 0,
-                               "stats": {k: v for k, v in st.as_dict().items() if not k.startswith(("lane_", "diag", "x_", "sh_"))}})
+                               "stats": {k: v for k, v in st.as_dict().items() if not k.startswith(("lane_", "diag", "x_", "sh_", "seg_"))}})
     # BSDF known answers
     rng = np.random.default_rng(3)
     n = 768

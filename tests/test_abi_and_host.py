@@ -29,7 +29,7 @@ def test_struct_sizes_match_header(pt):
     assert C.sizeof(pt.PtxObject) == 56
     assert C.sizeof(pt.PtxSceneDesc) == 96 and C.sizeof(pt.PtxTexture) == 16
     assert C.sizeof(pt.PtxHit) == 72
-    assert C.sizeof(pt.PtxStats) == 288   # 21 + 8 execution counters + 7 shading-divergence counters
+    assert C.sizeof(pt.PtxStats) == 320   # 21 + 8 execution counters + 7 shading-divergence counters + 4 segment-kernel phase clocks
     assert C.sizeof(pt.PtxBsdfCase) == 104
 
 
