@@ -121,6 +121,7 @@ struct DevScene {
 	int32_t num_tris;       // triangles in tri_geom / per plane of tri_soa
 	int32_t half_base;      // index of the first leaf-half record in `nodes` (behind all node records)
 	int32_t wide_stack;     // most entries a traversal of a wide tree can hold on its stack
+	int32_t num_materials, num_textures;
 };
 
 struct DevCamera {

@@ -103,10 +103,14 @@ struct MaterialRec {
 	float reflect_factor, refract_index, sharpness;
 };
 
-PT_DEV MaterialRec load_material(const DevScene& sc, int idx) {
-	const float4 m0 = sc.materials[3 * idx + 0];
-	const float4 m1 = sc.materials[3 * idx + 1];
-	const float4 m2 = sc.materials[3 * idx + 2];
+// `mats`: the scene's material table, or a copy of it in LDS (wf_segment_kernel: the table is small and sits in the middle
+// of a chain of dependent loads - state, triangle, material, texture descriptor, texel)
+PT_DEV MaterialRec load_material(const float4* mats, int idx);
+PT_DEV MaterialRec load_material(const DevScene& sc, int idx);
+PT_DEV MaterialRec load_material(const float4* mats, int idx) {
+	const float4 m0 = mats[3 * idx + 0];
+	const float4 m1 = mats[3 * idx + 1];
+	const float4 m2 = mats[3 * idx + 2];
 	MaterialRec m;
 	m.type = __float_as_int(m0.x);
 	m.color = mk3(m0.y, m0.z, m0.w);
@@ -117,8 +121,9 @@ PT_DEV MaterialRec load_material(const DevScene& sc, int idx) {
 	m.sharpness = m2.z;
 	return m;
 }
+PT_DEV MaterialRec load_material(const DevScene& sc, int idx) { return load_material(sc.materials, idx); }
 
-PT_DEV float4 hit_texel(const DevScene& sc, const HitInfo& hi, int texture) {
+PT_DEV float4 hit_texel(const DevScene& sc, const DevTexture* texs, const HitInfo& hi, int texture) {
 	const float4 s0 = sc.tri_shade[4 * hi.tri + 0];
 	const float4 s1 = sc.tri_shade[4 * hi.tri + 1];
 	const float4 s2 = sc.tri_shade[4 * hi.tri + 2];
@@ -126,14 +131,20 @@ PT_DEV float4 hit_texel(const DevScene& sc, const HitInfo& hi, int texture) {
 	// reference: src/radiance.cuh:74 texuv = bx*tx_a + by*tx_b + bz*tx_c
 	float tu = hi.bary.x * s0.w + hi.bary.y * s2.w + hi.bary.z * s3.y;
 	float tv = hi.bary.x * s1.w + hi.bary.y * s3.x + hi.bary.z * s3.z;
-	return tex_fetch(sc.textures[texture], tu, tv);
+	return tex_fetch(texs[texture], tu, tv);
 }
 
 // One path segment after a successful intersection (reference: src/radiance.cuh:36-83).
 // Returns true when the path ends here; `out` then holds the radiance to add.
+// `mats` / `texs`: the material and texture-descriptor tables to read (the scene's, or LDS copies).
 PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInfo& hi, Ray& ray, f3& mask,
-                          const u4& rnd, f3& out) {
-	const MaterialRec mat = load_material(sc, hi.material);
+                          const u4& rnd, f3& out, const float4* mats, const DevTexture* texs);
+PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInfo& hi, Ray& ray, f3& mask, const u4& rnd, f3& out) {
+	return shade_segment(sc, cam, hi, ray, mask, rnd, out, sc.materials, sc.textures);
+}
+PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInfo& hi, Ray& ray, f3& mask,
+                          const u4& rnd, f3& out, const float4* mats, const DevTexture* texs) {
+	const MaterialRec mat = load_material(mats, hi.material);
 	const bool textured = cam.texture_enabled && mat.texture > -1 && hi.tri >= 0;
 
 	if (cam.preview_mode) {
@@ -141,7 +152,7 @@ PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInf
 		f3 tex_color = mk3(0.0f);
 		float tex_blend = 0.0f, alpha = 0.0f;
 		if (textured) {
-			float4 texel = hit_texel(sc, hi, mat.texture);
+			float4 texel = hit_texel(sc, texs, hi, mat.texture);
 			alpha = texel.w;
 			tex_color = mk3(texel.x, texel.y, texel.z);
 			tex_blend = 0.5f;
@@ -154,6 +165,10 @@ PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInf
 		return true;
 	}
 
+	// the texel is fetched BEFORE the BSDF is sampled: the fetch is the last of a chain of dependent loads and the
+	// sampling below covers its round trip (the value is used after it, as in the reference: src/radiance.cuh:72-78)
+	float4 texel = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+	if (textured) texel = hit_texel(sc, texs, hi, mat.texture);
 	UniformStream rs;
 	rs.u[0] = u01(rnd.x); rs.u[1] = u01(rnd.y); rs.u[2] = u01(rnd.z); rs.u[3] = u01(rnd.w);
 	rs.next = 0;
@@ -164,7 +179,6 @@ PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInf
 		default: break;
 	}
 	if (textured) {
-		float4 texel = hit_texel(sc, hi, mat.texture);
 		mask = mask * (mk3(texel.x, texel.y, texel.z) * mat.color);
 	} else {
 		mask = mask * mat.color;

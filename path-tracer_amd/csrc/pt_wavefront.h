@@ -252,9 +252,21 @@ PT_DEV bool leaf_only_mesh_pairs(const DevScene& sc, const DevObject& ob, const 
 #define WF_SEG_OCC 4   // r2, with the pair filter of the single-leaf meshes: 128 registers, no spills: 6.61 ms per launch; at 5 waves/SIMD
                        // (96 registers, 33 spilled values) 7.29 ms. Without the filter: 7.13 ms at 5 (11 spilled), 7.25 at 4.
 #endif
-template <int FLAGS>
+// LDSTAB: the material table and the texture descriptors are copied into LDS first (the host picks this variant when
+// they fit): both are small, and both sit in the middle of the shading's chain of dependent loads
+#define WF_LDS_MATS 160
+#define WF_LDS_TEXS 64
+template <int FLAGS, int LDSTAB>
 __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevScene sc, DevCamera cam, WfParams wp) {
 	const int tid = threadIdx.x, lane = tid & 63;
+	__shared__ float4 sh_mats[LDSTAB ? 3 * WF_LDS_MATS : 1];
+	__shared__ DevTexture sh_texs[LDSTAB ? WF_LDS_TEXS : 1];
+	if (LDSTAB) {
+		for (int i = tid; i < 3 * sc.num_materials; i += PT_BLOCK) sh_mats[i] = sc.materials[i];
+		for (int i = tid; i < sc.num_textures; i += PT_BLOCK) sh_texs[i] = sc.textures[i];
+	}
+	const float4* mats = LDSTAB ? sh_mats : sc.materials;
+	const DevTexture* texs = LDSTAB ? sh_texs : sc.textures;
 	const int bounce = wp.bounce;
 	const int n_in = bounce == 0 ? wp.n_total : WF_CNT(wp, bounce - 1, 0);
 	const f3 cam_pos = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
@@ -361,12 +373,12 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 						if (FLAGS & PT_F_STATS) c_hm++;
 					}
 					if (FLAGS & PT_F_STATS) {
-						const MaterialRec mt = load_material(sc, hi.material);
+						const MaterialRec mt = load_material(mats, hi.material);
 						if (cam.texture_enabled && mt.texture > -1 && hi.tri >= 0) c_ht++;
 						shade_type = mt.type;
 					}
 					const u4 rnd = philox4x32_10(pixel, sample, (uint32_t)(bounce - 1), 0u, wp.k0, wp.k1);
-					done = shade_segment(sc, cam, hi, ray, mask, rnd, out);
+					done = shade_segment(sc, cam, hi, ray, mask, rnd, out, mats, texs);
 					if (!done && wp.is_last) { done = true; out = mk3(0.0f); } // bounce loop exhausted (:86)
 				}
 				if (done) {

@@ -59,7 +59,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
-	int wide_cfg, wide_scap, grp_mode;
+	int wide_cfg, wide_scap, grp_mode, seg_lds_tables;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -124,7 +124,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode, seg_lds_tables;
 	bool force_megakernel;
 };
 
@@ -145,6 +145,7 @@ static Tuning tuning_defaults() {
 	t.grp_pad_ppm = clampi(env_int("PTX_GRP_PAD_PPM", PT_GRP_PAD_PPM_DEFAULT), 0, 1000000);
 	// wide traversal (pt_wide.h): A/B configuration of the kernel and the most stack entries a lane may hold
 	t.grp_mode = clampi(env_int("PTX_GRP_MODE", 1), 0, 1);   // how a leaf's triangles are cut into groups of eight; read at scene upload
+	t.seg_lds_tables = env_int("PTX_SEG_LDS_TABLES", 1) != 0;
 	t.wide_cfg = env_int("PTX_WIDE_CFG", 0);
 	t.wide_scap = clampi(env_int("PTX_WIDE_SCAP", WFW_SCAP_MAX), 1, 32);
 	return t;
@@ -159,6 +160,7 @@ static void tune_defaults(PtxCtx* c) {
 	c->grp_pad_ppm = t.grp_pad_ppm;
 	c->wide_cfg = t.wide_cfg;
 	c->grp_mode = t.grp_mode;
+	c->seg_lds_tables = t.seg_lds_tables;
 	c->wide_scap = t.wide_scap;
 }
 
@@ -171,6 +173,7 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d.force_megakernel : value != 0;
 	else if (!strcmp(key, "grp_pad_ppm")) ctx->grp_pad_ppm = value < 0 ? d.grp_pad_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "grp_mode")) ctx->grp_mode = value < 0 ? d.grp_mode : clampi(value, 0, 1);
+	else if (!strcmp(key, "seg_lds_tables")) ctx->seg_lds_tables = value < 0 ? d.seg_lds_tables : (value != 0);
 	else if (!strcmp(key, "wide_cfg")) ctx->wide_cfg = value < 0 ? d.wide_cfg : value;
 	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
@@ -880,6 +883,8 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	s->dev.stack_entries = scene_max_depth < 1 ? 1 : scene_max_depth;
 	s->dev.half_base = (int32_t)half_base;
 	s->dev.wide_stack = wide_stack;
+	s->dev.num_materials = d->num_materials;
+	s->dev.num_textures = d->num_textures;
 	hipError_t e = hipStreamSynchronize(ctx->stream); // host vectors die at return
 	if (e != hipSuccess) { free_scene_allocs(s); delete s; return fail(PTX_E_HIP, "scene upload: %s", hipGetErrorString(e)); }
 	*out = s;
@@ -1138,9 +1143,13 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 			if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
 			prof_mark(ctx, 1);
 			if (collect_stats)
-				hipLaunchKernelGGL(wf_segment_kernel<PT_F_STATS>, dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+				hipLaunchKernelGGL((wf_segment_kernel<PT_F_STATS, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
 			else
-				hipLaunchKernelGGL(wf_segment_kernel<0>, dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+				// material / texture-descriptor tables in LDS when they fit (pt_wavefront.h)
+				if (ctx->seg_lds_tables && scene->dev.num_materials <= WF_LDS_MATS && scene->dev.num_textures <= WF_LDS_TEXS)
+					hipLaunchKernelGGL((wf_segment_kernel<0, 1>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+				else
+					hipLaunchKernelGGL((wf_segment_kernel<0, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
 			prof_mark(ctx, 1);
 			HIP_TRY(hipGetLastError());
 			if (wp.is_last) break;
