@@ -157,7 +157,8 @@ typedef struct PtxStats {
 	 *   x_unit_phases rounds with a leaf phase (unified: unit phases), x_turns commit / refill turns
 	 * wide traversal (pt_wide.h, variant 14): x_iters = visit iterations, x_item_lanes = wide-node visits, x_half_lanes =
 	 *   rays handed to the exact kernel (diag3 of them for a full stack), x_wait_lanes = stacked children dropped at the pop,
-	 *   x_unit_steps / x_units as above, x_unit_phases = drains; diag0..2 = clock ticks in turns / node visits / unit steps */
+	 *   x_unit_steps / x_units as above, x_unit_phases = drains; diag0..2 = clock ticks in turns / node visits / unit steps;
+	 *   lane_steps_active = rays handed to the exact kernel because their winning hit was not robust (pt_wide.h) */
 	uint64_t x_iters, x_item_lanes, x_half_lanes, x_wait_lanes, x_unit_steps, x_units, x_unit_phases, x_turns;
 	/* shading divergence in the segment kernel, counting variant only (the material-sorting question):
 	 * waves in which at least one lane shades a hit, the lanes that do, the BSDF branches (diffuse / specular /

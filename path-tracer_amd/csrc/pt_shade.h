@@ -123,11 +123,13 @@ PT_DEV MaterialRec load_material(const float4* mats, int idx) {
 }
 PT_DEV MaterialRec load_material(const DevScene& sc, int idx) { return load_material(sc.materials, idx); }
 
-PT_DEV float4 hit_texel(const DevScene& sc, const DevTexture* texs, const HitInfo& hi, int texture) {
-	const float4 s0 = sc.tri_shade[4 * hi.tri + 0];
-	const float4 s1 = sc.tri_shade[4 * hi.tri + 1];
-	const float4 s2 = sc.tri_shade[4 * hi.tri + 2];
-	const float4 s3 = sc.tri_shade[4 * hi.tri + 3];
+// `pre`: the triangle's four tri_shade words if the caller holds them already (else they are loaded here)
+struct TriShade { float4 s0, s1, s2, s3; bool held; };   // held: the caller has the record already
+PT_DEV float4 hit_texel(const DevScene& sc, const DevTexture* texs, const HitInfo& hi, int texture, const TriShade& pre) {
+	const float4 s0 = pre.held ? pre.s0 : sc.tri_shade[4 * hi.tri + 0];
+	const float4 s1 = pre.held ? pre.s1 : sc.tri_shade[4 * hi.tri + 1];
+	const float4 s2 = pre.held ? pre.s2 : sc.tri_shade[4 * hi.tri + 2];
+	const float4 s3 = pre.held ? pre.s3 : sc.tri_shade[4 * hi.tri + 3];
 	// reference: src/radiance.cuh:74 texuv = bx*tx_a + by*tx_b + bz*tx_c
 	float tu = hi.bary.x * s0.w + hi.bary.y * s2.w + hi.bary.z * s3.y;
 	float tv = hi.bary.x * s1.w + hi.bary.y * s3.x + hi.bary.z * s3.z;
@@ -138,12 +140,15 @@ PT_DEV float4 hit_texel(const DevScene& sc, const DevTexture* texs, const HitInf
 // Returns true when the path ends here; `out` then holds the radiance to add.
 // `mats` / `texs`: the material and texture-descriptor tables to read (the scene's, or LDS copies).
 PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInfo& hi, Ray& ray, f3& mask,
-                          const u4& rnd, f3& out, const float4* mats, const DevTexture* texs);
+                          const u4& rnd, f3& out, const float4* mats, const DevTexture* texs, const TriShade& pre_shade);
 PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInfo& hi, Ray& ray, f3& mask, const u4& rnd, f3& out) {
-	return shade_segment(sc, cam, hi, ray, mask, rnd, out, sc.materials, sc.textures);
+	TriShade none;
+	none.held = false;
+	none.s0 = none.s1 = none.s2 = none.s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	return shade_segment(sc, cam, hi, ray, mask, rnd, out, sc.materials, sc.textures, none);
 }
 PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInfo& hi, Ray& ray, f3& mask,
-                          const u4& rnd, f3& out, const float4* mats, const DevTexture* texs) {
+                          const u4& rnd, f3& out, const float4* mats, const DevTexture* texs, const TriShade& pre_shade) {
 	const MaterialRec mat = load_material(mats, hi.material);
 	const bool textured = cam.texture_enabled && mat.texture > -1 && hi.tri >= 0;
 
@@ -152,7 +157,7 @@ PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInf
 		f3 tex_color = mk3(0.0f);
 		float tex_blend = 0.0f, alpha = 0.0f;
 		if (textured) {
-			float4 texel = hit_texel(sc, texs, hi, mat.texture);
+			float4 texel = hit_texel(sc, texs, hi, mat.texture, pre_shade);
 			alpha = texel.w;
 			tex_color = mk3(texel.x, texel.y, texel.z);
 			tex_blend = 0.5f;
@@ -168,7 +173,7 @@ PT_DEV bool shade_segment(const DevScene& sc, const DevCamera& cam, const HitInf
 	// the texel is fetched BEFORE the BSDF is sampled: the fetch is the last of a chain of dependent loads and the
 	// sampling below covers its round trip (the value is used after it, as in the reference: src/radiance.cuh:72-78)
 	float4 texel = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-	if (textured) texel = hit_texel(sc, texs, hi, mat.texture);
+	if (textured) texel = hit_texel(sc, texs, hi, mat.texture, pre_shade);
 	UniformStream rs;
 	rs.u[0] = u01(rnd.x); rs.u[1] = u01(rnd.y); rs.u[2] = u01(rnd.z); rs.u[3] = u01(rnd.w);
 	rs.next = 0;

@@ -17,6 +17,18 @@
 // therefore NOT decided here: it goes to the retry queue and is traversed again, from its untouched state, by the
 // exact kernel (wf_traverse_coop_kernel with wp.use_retry). The same exit serves rays whose stack would overflow.
 //
+// The argument above needs the hit POINT of every accepted triangle to lie inside the boxes that hold the triangle.
+// At grazing incidence (cos ~ 1e-4) the reference's t = f * dot(e2, q) loses most of its digits (f = 1 / det is huge):
+// tools/grazing_stress.py finds triangles the reference "hits" 0.005 ... 0.25 units in FRONT of where the ray meets
+// them, i.e. in front of their own boxes. Such a hit can beat a well-conditioned one although its box lies behind it,
+// and one traversal may test the triangle where the other has culled its box by distance. Two measures:
+//   * distance culling keeps a margin: a box is dropped only if the ray enters it beyond best t x cull_rel + cull_abs,
+//     so triangles just behind the best hit are still tested;
+//   * a WINNING hit whose point is not inside its triangle's own (slightly widened) vertex box sends its ray to the exact
+//     kernel (checked at the commit, where the winner's record is read once more for its u, v).
+// With both, the grazing stress (400 000 rays per scene) shows no difference from the oracle; without them 3 rays of the
+// car and 2 of the triangle soup differed.
+//
 // Structure (wave-uniform control flow):
 //   * one ray per lane walks wide nodes: one 64-B record = four child boxes in 8 bits relative to their union
 //     + four links (node index | 0x80000000 + group | -1). Children that are nodes are visited nearest first
@@ -33,13 +45,13 @@
 #include "pt_wavefront.h"
 
 #define WFW_UNIT_CAP 320
-#define WFW_WAVE_BYTES (64 * 8 + 64 * 8 + 64 * 4 + WFW_UNIT_CAP * 4)   /* keys, (u, v), flags, units */
+#define WFW_WAVE_BYTES (64 * 8 + 64 * 4 + WFW_UNIT_CAP * 4)   /* keys, flags, units */
 #define WFW_BYTES ((PT_BLOCK / 64) * WFW_WAVE_BYTES)
 #define WFW_STACK_ENTRY_BYTES 6                                         /* link (4) + entry distance as bf16 (2) */
 #define WFW_SCAP_MAX 10   /* 10 x 6 B x 256 lanes + the waves' areas = 25.6 KB per workgroup: six workgroups per CU */
 
 template <int FLAGS, int OCC, int CHUNK, int TURN_MIN, int DRAIN_MIN, int KNOB = 0>
-__global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index, int scap) {
+__global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index, int scap, float cull_rel, float cull_abs) {
 	static_assert(CHUNK >= 1 && CHUNK <= 128, "a chunk's queue entries are held two per lane");
 	static_assert(DRAIN_MIN >= 16 && DRAIN_MIN <= 64 && 63 + 256 < WFW_UNIT_CAP, "the unit list must hold one more iteration's appends");
 	extern __shared__ int lds_stack[];
@@ -48,23 +60,22 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 	unsigned short* sdist = reinterpret_cast<unsigned short*>(lds_stack + scap * PT_BLOCK) + tid;   // entry i at sdist[i * PT_BLOCK]
 	unsigned char* area = reinterpret_cast<unsigned char*>(lds_stack) + (size_t)scap * PT_BLOCK * WFW_STACK_ENTRY_BYTES + (tid >> 6) * WFW_WAVE_BYTES;
 	unsigned long long* keys = reinterpret_cast<unsigned long long*>(area);      // per lane: (t bits << 32 | triangle) of its best hit
-	float2* uvs = reinterpret_cast<float2*>(area + 64 * 8);                      // (u, v) of the triangle behind the key
-	uint32_t* flags = reinterpret_cast<uint32_t*>(area + 64 * 16);               // != 0: the best t was reached from two blocks
-	uint32_t* units = reinterpret_cast<uint32_t*>(area + 64 * 20);               // owner lane | group << 6
+	uint32_t* flags = reinterpret_cast<uint32_t*>(area + 64 * 8);                // != 0: the best t was reached from two blocks
+	uint32_t* units = reinterpret_cast<uint32_t*>(area + 64 * 12);               // owner lane | group << 6
 	const int n = WF_CNT(wp, wp.bounce, 1 + slot_index);
 	const int* __restrict__ queue = wp.queue[slot_index];
 	const float4* __restrict__ wn = sc.wide_nodes;
 	const float4* __restrict__ tg = sc.tri_grp;
 	const int root = sc.wide_root[obj_index];
 	const unsigned long long lt = (1ull << lane) - 1ull;
-	uint64_t n_taken = 0, act = 0, tot = 0;
+	uint64_t n_taken = 0, tot = 0;
 	// PtxStats.x_*: visit iterations, lanes visiting in them, rays sent to the retry queue, stacked nodes dropped at the
 	// pop, unit steps, units, drains, commit / refill turns
 	uint64_t x_iters = 0, x_item = 0, x_retry = 0, x_drop = 0, x_usteps = 0, x_units = 0, x_drains = 0, x_turns = 0;
 	// counting variant only: constant-rate clock read by lane 0, summed per phase into PtxStats.diag0..2 (turns without their
 	// unit steps, node visits, unit steps); diag3 = rays retried because their stack was full (the others: equal t)
 #define WFW_CLOCK() (((FLAGS & PT_F_STATS) && lane == 0) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
-	uint64_t dg_turn = 0, dg_visit = 0, dg_unit = 0, dg_over = 0;
+	uint64_t dg_turn = 0, dg_visit = 0, dg_unit = 0, dg_over = 0, x_fragile = 0;
 
 	WaveFeed feed;
 	feed.exhausted = false;
@@ -75,7 +86,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 	int state = IDLE;
 	int path = 0, curr = 0, sp = 0, cur_obj_r = -1;
 	bool redo = false;
-	float cur_d = 0.0f, tmin = 0.0f;
+	float cur_d = 0.0f, tmin = 0.0f;   // tmin: the CULLING bound = best t so far x cull_rel + cull_abs (see the header comment)
 	f3 o = mk3(0.0f), d = mk3(1.0f), inv = mk3(1.0f);
 	int nunits = 0;   // wave-uniform
 	int qa = 0, qb = 0, feed_base = 0;   // queue entries feed_base + lane and feed_base + 64 + lane of the wave's chunk
@@ -106,7 +117,6 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 				e2.x = (v2f){c3.x, c3.y}; e2.y = (v2f){c3.z, c3.w}; e2.z = (v2f){c4.x, c4.y};
 				v2f t, u, v;
 				const uint32_t hb = tri_test_flat_x2(bo, bd, va, e1, e2, t, u, v);
-				if (FLAGS & PT_F_STATS) act += 2;
 				if (__ballot(hb != 0u) != 0ull) {
 					// a hit has t > 5e-8, so its bit pattern orders like its value; 0xffffffff = no hit
 					const uint32_t k0 = (hb & 1u) ? __float_as_uint(t.x) : 0xffffffffu;
@@ -121,15 +131,14 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 						// the same t from another 32-slot block (= possibly another leaf): the reference's visiting
 						// order decides, which this kernel does not know
 						if ((uint32_t)(old >> 32) == k && (((uint32_t)old ^ cand) >> 5) != 0u) flags[owner] = 1u;
-						if (keys[owner] == key) uvs[owner] = win0 ? make_float2(u.x, v.x) : make_float2(u.y, v.y);
 					}
 				}
 			}
 			nunits = base;
 		}
 		__builtin_amdgcn_wave_barrier();
-		// owners lower their culling bound to the best t so far (a NaN pattern = no hit yet leaves it)
-		if (state == DESCEND) tmin = __builtin_fminf(tmin, __uint_as_float(reinterpret_cast<const uint32_t*>(keys)[2 * lane + 1]));
+		// owners lower their culling bound: the best t so far plus the margin (a NaN pattern = no hit yet leaves it)
+		if (state == DESCEND) tmin = __builtin_fminf(tmin, __builtin_fmaf(__uint_as_float(reinterpret_cast<const uint32_t*>(keys)[2 * lane + 1]), cull_rel, cull_abs));
 		dg_unit += WFW_CLOCK() - cu0;
 	};
 
@@ -148,14 +157,36 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 				if (!again && key != ~0ull) {
 					const float t = __uint_as_float((uint32_t)(key >> 32));
 					if (t < __builtin_huge_valf()) {
+						// The winner once more, from its plain record: (u, v) are the test's own values (same operations,
+						// same bits as in the unit step), and the vertices decide whether the hit is ROBUST: its point o + t d
+						// must lie in the box of the triangle's own vertices, widened by less than any tree's padding. Then
+						// every box that holds the triangle, here and in the reference's tree, holds the point, and both
+						// traversals test the triangle unless it lies beyond their best hit anyway. A winner that is not (t off
+						// through cancellation at grazing incidence) may have been culled by the reference: exact kernel.
+						const int tri = (int)(uint32_t)key;
+						const float4 a4 = sc.tri_soa[tri], f4 = sc.tri_soa[sc.num_tris + tri], g4 = sc.tri_soa[2 * (size_t)sc.num_tris + tri];
+						Ray rr;
+						rr.o = o; rr.d = d; rr.inv = inv; rr.sx = rr.sy = rr.sz = false;
+						float t_, u_, v_;
+						(void)tri_test_flat(rr, mk3(a4.x, a4.y, a4.z), mk3(f4.x, f4.y, f4.z), mk3(g4.x, g4.y, g4.z), t_, u_, v_);
+						bool bad = false;
+#define WFW_AXIS(C) { \
+						const float p_ = __builtin_fmaf(t, d.C, o.C); \
+						const float rho_ = __builtin_fmaf(4.8e-7f, __builtin_fabsf(p_), 3e-5f); \
+						const float lo_ = a4.C + __builtin_fminf(0.0f, __builtin_fminf(f4.C, g4.C)), hi_ = a4.C + __builtin_fmaxf(0.0f, __builtin_fmaxf(f4.C, g4.C)); \
+						bad |= !(p_ >= lo_ - rho_ && p_ <= hi_ + rho_); }
+						WFW_AXIS(x) WFW_AXIS(y) WFW_AXIS(z)
+#undef WFW_AXIS
 						const f3 p = o + t * d;
 						const float dist = length3(p - o);
-						if (dist < cur_d || (dist == cur_d && cur_obj_r >= 0 && obj_index < cur_obj_r)) {
-							const float2 w = uvs[lane];
+						if (bad) {
+							again = true;
+							if (FLAGS & PT_F_STATS) x_fragile++;
+						} else if (dist < cur_d || (dist == cur_d && cur_obj_r >= 0 && obj_index < cur_obj_r)) {
 							wp.s0[path].w = dist;
 							wp.s1[path].w = t;
 							wp.s2[path].w = __int_as_float(obj_index);
-							store_hit(wp.s3 + path, (int)(uint32_t)key, w.x, w.y);
+							store_hit(wp.s3 + path, tri, u_, v_);
 						}
 					}
 				}
@@ -219,7 +250,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		dg_turn += (ct1 - ct0) - (dg_unit - du0);
 		const uint64_t du1 = dg_unit;
 		// ---- one wide node per descending lane ----
-		if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; x_iters++; } if (state == DESCEND) { x_item++; act++; } }
+		if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; x_iters++; } if (state == DESCEND) x_item++; }
 		uint32_t gh = 0;          // bit k: child k is a group and the ray touches its box
 		int gref0 = 0, gref1 = 0, gref2 = 0, gref3 = 0;
 		if (state == DESCEND) {
@@ -328,7 +359,8 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		}
 		dg_visit += (WFW_CLOCK() - ct1) - (dg_unit - du1);
 	}
-	stats_flush(wp.stats, TraceCounters{0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
+	// lane_steps_active of this kernel = rays sent to the exact kernel because their winning hit was not robust
+	stats_flush(wp.stats, TraceCounters{0, 0, 0, 0, 0, 0}, 0, 0, 0, 0, 0, x_fragile, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
 	if (FLAGS & PT_F_STATS) {
 		exec_flush(wp.stats, x_iters, x_item, x_retry, x_drop, x_usteps, x_units, x_drains, x_turns);
 		diag_flush(wp.stats, dg_turn, dg_visit, dg_unit, dg_over);

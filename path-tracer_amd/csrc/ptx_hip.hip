@@ -59,7 +59,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
-	int wide_cfg, wide_scap, grp_mode, seg_lds_tables;
+	int wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -124,7 +124,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode, seg_lds_tables;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm;
 	bool force_megakernel;
 };
 
@@ -146,6 +146,8 @@ static Tuning tuning_defaults() {
 	// wide traversal (pt_wide.h): A/B configuration of the kernel and the most stack entries a lane may hold
 	t.grp_mode = clampi(env_int("PTX_GRP_MODE", 1), 0, 1);   // how a leaf's triangles are cut into groups of eight; read at scene upload
 	t.seg_lds_tables = env_int("PTX_SEG_LDS_TABLES", 1) != 0;
+	// margin of the wide traversal's distance culling, relative to the best t (and absolute), in parts per million (pt_wide.h)
+	t.wide_margin_ppm = clampi(env_int("PTX_WIDE_MARGIN_PPM", 10000), 0, 1000000);
 	t.wide_cfg = env_int("PTX_WIDE_CFG", 0);
 	t.wide_scap = clampi(env_int("PTX_WIDE_SCAP", WFW_SCAP_MAX), 1, 32);
 	return t;
@@ -160,6 +162,7 @@ static void tune_defaults(PtxCtx* c) {
 	c->grp_pad_ppm = t.grp_pad_ppm;
 	c->wide_cfg = t.wide_cfg;
 	c->grp_mode = t.grp_mode;
+	c->wide_margin_ppm = t.wide_margin_ppm;
 	c->seg_lds_tables = t.seg_lds_tables;
 	c->wide_scap = t.wide_scap;
 }
@@ -174,6 +177,7 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "grp_pad_ppm")) ctx->grp_pad_ppm = value < 0 ? d.grp_pad_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "grp_mode")) ctx->grp_mode = value < 0 ? d.grp_mode : clampi(value, 0, 1);
 	else if (!strcmp(key, "seg_lds_tables")) ctx->seg_lds_tables = value < 0 ? d.seg_lds_tables : (value != 0);
+	else if (!strcmp(key, "wide_margin_ppm")) ctx->wide_margin_ppm = value < 0 ? d.wide_margin_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "wide_cfg")) ctx->wide_cfg = value < 0 ? d.wide_cfg : value;
 	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
@@ -1005,7 +1009,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	//   15: leaf mode 9 alone (the default before the wide traversal)
 	const int scap = scene->dev.wide_stack < ctx->wide_scap ? scene->dev.wide_stack : ctx->wide_scap;
 	const size_t wide_lds = (size_t)scap * PT_BLOCK * WFW_STACK_ENTRY_BYTES + WFW_BYTES;
-#define WIDEK(F, O, T, D, ...) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, O, WF_CHUNK, T, D, ##__VA_ARGS__>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap)
+#define WIDEK(F, O, T, D, ...) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, O, WF_CHUNK, T, D, ##__VA_ARGS__>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap, 1.0f + 1e-6f * (float)ctx->wide_margin_ppm, 1e-6f * (float)ctx->wide_margin_ppm)
 	// <stats, waves/SIMD for the register allocator, -, lanes that must wait before a turn, units that must gather before a drain>
 #define WIDE(F) switch (ctx->wide_cfg) { \
 		case 1: WIDEK(F, 5, 8, 32, 4); break;    /* the first default: 5 waves, turn at 8, split refill */ \

@@ -23,5 +23,5 @@ print("unit steps %d: fill %.1f of 16; drains %d (%.1f units each); turns %d (%.
       (d["x_unit_steps"], d["x_units"] / max(1, d["x_unit_steps"]), d["x_unit_phases"], d["x_units"] / max(1, d["x_unit_phases"]),
        d["x_turns"], it / max(1, d["x_turns"])))
 tot = float(d["diag0"] + d["diag1"] + d["diag2"]) or 1.0
-print("clock share: turns %.1f%%  node visits %.1f%%  unit steps %.1f%%;  retried for a full stack: %d" %
-      (100 * d["diag0"] / tot, 100 * d["diag1"] / tot, 100 * d["diag2"] / tot, d["diag3"]))
+print("clock share: turns %.1f%%  node visits %.1f%%  unit steps %.1f%%;  retried for a full stack: %d, for a winning hit that is not robust: %d" %
+      (100 * d["diag0"] / tot, 100 * d["diag1"] / tot, 100 * d["diag2"] / tot, d["diag3"], d["lane_steps_active"]))
