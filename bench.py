@@ -276,7 +276,7 @@ def main():
     # and the exact kernel's retry launch behind it). Since the wide traversal they take about the same time on the
     # headline scene, so the dominant one is whichever is larger in THIS run and the other is reported beside it.
     trav = kernel_view("wf_traverse_wide_kernel<0,", trav_ms.value, trav_n.value) if trav_n.value > 0 else None
-    seg = kernel_view("wf_segment_kernel<0>", seg_ms.value, seg_n.value)
+    seg = kernel_view("wf_segment_kernel<0,", seg_ms.value, seg_n.value)
     trav_dominant = trav is not None and trav_ms.value >= seg_ms.value
     dom, other = (trav, seg) if trav_dominant else (seg, trav)
     trav_s = max(float(trav_ms.value) * 1e-3, 1e-12)
