@@ -319,7 +319,7 @@ def main():
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # on rank 0 at N = 1 only
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
         # A one-GPU job's share of the host is 16 cores (the box's rule for worker pools), however many
