@@ -44,10 +44,13 @@
 #endif
 #define PT_WF_MAX_BOUNCES 64
 
+// parked radiance of a finished path (12 B: the fourth word of a float4 would be a quarter of this buffer's traffic)
+struct Rad3 { float x, y, z; };
+
 struct WfParams {
 	float4* s0; float4* s1; float4* s2; float4* s3;         // state set this bounce WRITES (and its traversals update)
 	const float4* i0; const float4* i1; const float4* i2; const float4* i3;   // state set of the previous bounce (read)
-	float4* rad;              // [batch][npix]
+	Rad3* rad;                // [batch][npix], 12 B each: a finished path parks its radiance here
 	int* queue[PT_MAX_BIG];   // per multi-node mesh: slots (in s0..s3) of the paths whose ray enters its root box
 	int* retry;               // slots of the rays the wide traversal (pt_wide.h) hands to the exact kernel; shared by the queues in turn
 	int use_retry;            // wf_traverse_coop_kernel: take the rays from `retry` instead of queue[slot]
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 		if (x >= cam.width || y >= cam.height) alive = false;
 		const uint32_t pixel = (uint32_t)(x + y * cam.width);
 		const uint32_t sample = (uint32_t)(wp.first_sample + sl);
-		float4* rad_slot = wp.rad + (size_t)sl * (size_t)wp.npix + pixel;
+		Rad3* rad_slot = wp.rad + (size_t)sl * (size_t)wp.npix + pixel;
 
 		Ray ray;
 		f3 mask = mk3(1.0f);
@@ -334,7 +337,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 				pixel_midpoint(cam, x, y, mid, centre);
 				init_ray(ray, cam_pos, jittered_dir(cam, mid, pixel, sample, wp.k0, wp.k1));
 				if (wp.is_last) { // max_ray_bounces == 0: the bounce loop never runs
-					*rad_slot = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					*rad_slot = Rad3{0.0f, 0.0f, 0.0f};
 					n_paths++;
 					alive = false;
 				}
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 					if (!done && wp.is_last) { done = true; out = mk3(0.0f); } // bounce loop exhausted (:86)
 				}
 				if (done) {
-					*rad_slot = make_float4(out.x, out.y, out.z, 0.0f);
+					*rad_slot = Rad3{out.x, out.y, out.z};
 					n_paths++;
 					alive = false;
 				}
@@ -1419,13 +1422,13 @@ __global__ __launch_bounds__(PT_BLOCK) void wfq_result_kernel(DevScene sc, WfPar
 }
 
 // reference: src/pathtracing.cu:151 acc_image[index] += make_float4(radiance), once per iteration, in order
-__global__ __launch_bounds__(PT_BLOCK) void wf_accumulate_kernel(float4* __restrict__ accum, const float4* __restrict__ rad,
+__global__ __launch_bounds__(PT_BLOCK) void wf_accumulate_kernel(float4* __restrict__ accum, const Rad3* __restrict__ rad,
                                                                  int npix, int batch) {
 	const int p = blockIdx.x * PT_BLOCK + threadIdx.x;
 	if (p >= npix) return;
 	float4 acc = accum[p];
 	for (int s = 0; s < batch; ++s) {
-		const float4 r = rad[(size_t)s * (size_t)npix + p];
+		const Rad3 r = rad[(size_t)s * (size_t)npix + p];
 		acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += 0.0f;
 	}
 	accum[p] = acc;

@@ -236,7 +236,7 @@ static int wf_ensure(PtxCtx* c, size_t paths, size_t rad, int queues) {
 	HIP_TRY(hipMalloc((void**)&c->wf.s2, paths * sizeof(float4)));
 	HIP_TRY(hipMalloc((void**)&c->wf.s3, paths * sizeof(float4)));
 	for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&c->wf_b[k], paths * sizeof(float4)));
-	HIP_TRY(hipMalloc((void**)&c->wf.rad, rad * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.rad, rad * sizeof(Rad3)));
 	for (int k = 0; k < queues; ++k) HIP_TRY(hipMalloc((void**)&c->wf.queue[k], paths * sizeof(int)));
 	HIP_TRY(hipMalloc((void**)&c->wf.counters, WF_COUNTER_INTS * sizeof(int))); // counts + traversal cursors, queues and retry queues
 	if (queues > 0) HIP_TRY(hipMalloc((void**)&c->wf.retry, paths * sizeof(int)));
@@ -1165,7 +1165,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 			}
 		}
 		hipLaunchKernelGGL(wf_accumulate_kernel, dim3((unsigned)((npix + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream,
-		                   ctx->accum, (const float4*)wp.rad, (int)npix, b);
+		                   ctx->accum, (const Rad3*)wp.rad, (int)npix, b);
 		HIP_TRY(hipGetLastError());
 	}
 	return PTX_OK;
