@@ -155,3 +155,58 @@ def test_fragile_hits_at_grazing_incidence_equal_the_oracle(pt, orc, ctx):
                 assert len(bad) == 0, f"variant {variant}: {k} differs for {len(bad)} rays, first {bad[:5]}"
     finally:
         _tune(pt, ctx, b"trav_variant", -1)
+
+
+@pytest.mark.parametrize("seed", list(range(11, 27)))
+def test_random_soups_render_like_the_oracle(pt, orc, ctx, tmp_path, seed):
+    """Fuzz: triangle soups of random size, density and triangle shape (needles and slivers included), a random
+    camera inside or outside the cloud, mirrors and glass among the materials so that secondary rays start on
+    surfaces and leave in all directions: accumulation buffers and ray-by-ray hits of the wide traversal equal
+    the oracle bit for bit."""
+    rng = np.random.default_rng(seed)
+    n_tris = int(rng.integers(300, 6000))
+    spread = float(10.0 ** rng.uniform(-0.5, 1.0))
+    c = rng.uniform(-spread, spread, (n_tris, 3))
+    size = 10.0 ** rng.uniform(-2.5, 0.0, (n_tris, 1, 1)) * spread
+    v = c[:, None, :] + size * rng.normal(size=(n_tris, 3, 3)) * rng.uniform(0.02, 1.0, (n_tris, 1, 3))
+    mats = ["white.diff", "mirror.spec", "glass.trans"]
+    lines = ["mtllib m.mtl"]
+    for tri in v:
+        for q in tri:
+            lines.append("v %.9g %.9g %.9g" % tuple(q))
+    for i in range(n_tris):
+        if i % 97 == 0:
+            lines.append("usemtl " + mats[(i // 97) % 3])
+        lines.append("f %d %d %d" % (3 * i + 1, 3 * i + 2, 3 * i + 3))
+    (tmp_path / "soup.obj").write_text("\n".join(lines) + "\n")
+    (tmp_path / "m.mtl").write_text("newmtl white.diff\nKd 0.8 0.7 0.6\nnewmtl mirror.spec\nKd 0.9 0.9 0.9\nNs 600\nd 0.7\n"
+                                    "newmtl glass.trans\nKd 0.95 0.95 0.95\nNi 1.5\nd 0.1\n")
+    pos = rng.uniform(-1.5, 1.5, 3) * spread
+    look = -pos + rng.normal(0, 0.2 * spread, 3)
+    look /= np.linalg.norm(look)
+    (tmp_path / "s.json").write_text(
+        '{"camera": {"pixelWidth": 80, "pixelHeight": 56, "direction": [%.6f,%.6f,%.6f], "up": [0,1,0], "position": [%.6f,%.6f,%.6f],'
+        ' "screenDist": 1.2, "screenHeight": 2}, "objects": ['
+        '{"type": "sphere", "render": true, "radius": %.6f, "position": [0, 0, 0], "material": {"type": "lumi", "Kd": [1], "Ke": [3]}},'
+        '{"type": "mesh", "render": true, "src": "%s"}]}' % (*look, *pos, 30.0 * spread, tmp_path / "soup.obj"))
+    desc, cam = pt.load_scene(str(tmp_path / "s.json"))
+    assert desc.contents.num_nodes > 3
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 0, 6, seed)
+    acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 6, seed)
+    bad = np.nonzero((acc_o.view(np.uint32) != acc_g.view(np.uint32)).any(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} pixels differ, first {bad[:5]}"
+    assert st_o.rays == st_g.rays and st_o.paths == st_g.paths
+    # ray by ray: primary rays and rays from random points inside the cloud in random directions
+    o1, d1 = orc.generate_rays(cam, -1, 0)
+    n2 = 20000
+    o2 = rng.uniform(-spread, spread, (n2, 3)).astype(np.float32)
+    d2 = rng.normal(size=(n2, 3))
+    d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+    o, dd = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    ho, hq = orc.trace(desc, o, dd, 1), gpuops.trace_queued(ctx, scene, o, dd, 1)
+    assert (ho["hit"] == 1).sum() > 100
+    for k in ("object", "prim", "t_bits", "bary"):
+        badr = np.nonzero((ho[k] != hq[k]).reshape(len(o), -1).any(axis=1))[0]
+        assert len(badr) == 0, f"{k} differs for {len(badr)} rays, first {badr[:5]}"
