@@ -59,6 +59,9 @@ struct WfParams {
 	int first_sample, batch;
 	int npt;                  // padded pixels per sample = tiles * 64
 	int tiles_x, npix, n_total;
+	// n / npt and n / tiles_x for n < 2^28 as mulhi(n, m) >> s (wf_magic_div on the host): a vector integer division is some
+	// twenty instructions, and the segment kernel did two per path
+	uint32_t npt_m, npt_s, tx_m, tx_s;
 	uint32_t k0, k1;
 	int bounce, is_last;
 	int num_big;
@@ -319,10 +322,11 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 			}
 		}
 		// path id -> (sample, pixel): sample-major, then 8x8 tiles, lane = x + 8 y inside the tile
-		const int sl = path / wp.npt, r = path - sl * wp.npt;
+		const int sl = wp.npt == 1 ? path : (int)(__umulhi((uint32_t)path, wp.npt_m) >> wp.npt_s), r = path - sl * wp.npt;
 		const int tile = r >> 6, l = r & 63;
-		const int x = (tile % wp.tiles_x) * 8 + (l & 7);
-		const int y = (tile / wp.tiles_x) * 8 + (l >> 3);
+		const int trow = wp.tiles_x == 1 ? tile : (int)(__umulhi((uint32_t)tile, wp.tx_m) >> wp.tx_s);
+		const int x = (tile - trow * wp.tiles_x) * 8 + (l & 7);
+		const int y = trow * 8 + (l >> 3);
 		if (x >= cam.width || y >= cam.height) alive = false;
 		const uint32_t pixel = (uint32_t)(x + y * cam.width);
 		const uint32_t sample = (uint32_t)(wp.first_sample + sl);

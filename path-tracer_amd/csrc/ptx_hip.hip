@@ -970,6 +970,18 @@ extern "C" int ptx_accum_clear(PtxCtx* ctx) {
 	return PTX_OK;
 }
 
+// Division of n < 2^28 by a launch-uniform d in [2, 2^28] as mulhi(n, m) >> s: with L = ceil(log2 d) and k = 31 + L,
+// m = floor(2^k / d) + 1 < 2^32 and the error n (m d - 2^k) <= n d < 2^(28 + L) < 2^k, so the quotient is exact
+// (checked against n / d in ptx_render_samples for the launch's extreme n). d = 1 has no such pair: the kernel tests for it.
+static void wf_magic_div(uint32_t d, uint32_t* m, uint32_t* s) {
+	if (d <= 1) { *m = 0; *s = 0; return; }
+	uint32_t L = 0;
+	while (((uint64_t)1 << L) < d) ++L;
+	const uint32_t k = 31 + L;
+	*m = (uint32_t)((((uint64_t)1 << k) / d) + 1);
+	*s = k - 32;
+}
+
 static size_t stack_lds_bytes(const PtxScene* s) { return (size_t)s->dev.stack_entries * PT_BLOCK * sizeof(int); }
 
 static int check_scene(const PtxCtx* ctx, const PtxScene* scene, const char* who) {
@@ -1129,6 +1141,8 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		wp.batch = b;
 		wp.npt = (int)npt;
 		wp.tiles_x = tiles_x;
+		wf_magic_div((uint32_t)npt, &wp.npt_m, &wp.npt_s);
+		wf_magic_div((uint32_t)tiles_x, &wp.tx_m, &wp.tx_s);
 		wp.npix = (int)npix;
 		wp.n_total = (int)(npt * (size_t)b);
 		wp.k0 = k0; wp.k1 = k1;
