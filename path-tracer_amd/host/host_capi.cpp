@@ -194,6 +194,27 @@ extern "C" unsigned int pth_wang_hash(unsigned int x) { return wang_hash(x); }
 extern "C" unsigned int pth_wang_unhash(unsigned int h) { return wang_unhash(h); }
 extern "C" float pth_fmedian(float* arr, int n) { return fmedian(arr, n); }
 
+extern "C" void pth_transform_compose(const float* ops, int n, float* m16, float* normal16) {
+	std::vector<TransformStep> steps((size_t)(n > 0 ? n : 0));
+	for (int i = 0; i < n; ++i) {
+		steps[(size_t)i].kind = (int)ops[5 * i];
+		for (int k = 0; k < 4; ++k) steps[(size_t)i].v[k] = ops[5 * i + 1 + k];
+	}
+	const glmlite::mat4 m = composeTransform(steps.data(), n);
+	const glmlite::mat4 nm = glmlite::transpose(glmlite::inverse(m)); // what loadTriangleMeshObj applies to normals
+	memcpy(m16, &m.c[0].x, 16 * sizeof(float));
+	memcpy(normal16, &nm.c[0].x, 16 * sizeof(float));
+}
+
+extern "C" void pth_transform_apply(const float* m16, const float* v3, int n, float* out4) {
+	glmlite::mat4 m;
+	memcpy(&m.c[0].x, m16, 16 * sizeof(float));
+	for (int i = 0; i < n; ++i) {
+		const glmlite::vec4 r = glmlite::mul(m, glmlite::vec4{v3[3 * i], v3[3 * i + 1], v3[3 * i + 2], 1.0f});
+		out4[4 * i] = r.x; out4[4 * i + 1] = r.y; out4[4 * i + 2] = r.z; out4[4 * i + 3] = r.w;
+	}
+}
+
 extern "C" int pth_load_image_float(const char* path, int* w, int* h, int* channels, float** pixels_out) {
 	std::vector<float> px;
 	std::string err;

@@ -45,6 +45,10 @@ void pth_shutdown(void);
 int pth_kd_build(const float* abc, int n, PtxKDNode** nodes_out, int32_t** leaf_tris_out, int* num_leaf_tris_out, int* max_depth_out);
 void pth_free(void* p);
 float pth_fmedian(float* arr, int n);
+/* mesh transforms as the loader composes and applies them (world_load.cpp composeTransform, glmlite.h); ops = n records
+ * of 5 floats (kind 0 translate / 1 rotate degrees+axis / 2 scale, then 4 numbers); m16 column-major, normal16 = transpose(inverse(M)) */
+void pth_transform_compose(const float* ops, int n, float* m16, float* normal16);
+void pth_transform_apply(const float* m16, const float* v3, int n, float* out4);
 
 /* image helpers */
 int pth_load_image_float(const char* path, int* w, int* h, int* channels, float** pixels_out);

@@ -71,70 +71,117 @@ static std::string resolvePath(const std::string& p) {
 	return asset_root + s;
 }
 
-// reference: src/world_load.cpp:41-115
+// One place where the five MTL-style numbers become a Material, for sphere objects (JSON "material" block) and
+// for mesh materials (MTL records) alike. Semantics: reference src/world_load.cpp:62-69 and :264-269 —
+// Kd -> color, Ke -> emittance, d -> reflect_factor, Ni -> refract_index, sharpness = clamp(Ns / 1000, 0, 1).
+struct MaterialFields {
+	MaterialType type;
+	float3 Kd, Ke;
+	float d, Ni, Ns;
+};
+
+static Material makeMaterial(const MaterialFields& f, int texture) {
+	Material m;
+	m.type = f.type;
+	m.color = f.Kd;
+	m.cuda_texture_obj = texture;
+	m.emittance = f.Ke;
+	m.reflect_factor = f.d;
+	m.refract_index = f.Ni;
+	m.sharpness = clampf(f.Ns / 1000.0f, 0.0f, 1.0f);
+	return m;
+}
+
+// A mesh's "transform" list as plain records (kind, 4 numbers): kind 0 translate(x,y,z), 1 rotate(degrees, axis),
+// 2 scale(x,y,z). Entries that are not single-member objects, and members with other names ("xrotate" ...), are
+// skipped as the reference skips them (src/world_load.cpp:86-101).
+static std::vector<TransformStep> readTransformList(const Json::Value& jlist) {
+	std::vector<TransformStep> steps;
+	if (!jlist.isArray()) return steps;
+	for (unsigned t = 0; t < jlist.size(); ++t) {
+		const Json::Value& entry = jlist[t];
+		if (!entry.isObject() || entry.size() != 1) continue;
+		const std::string key = entry.getMemberNames()[0];
+		const Json::Value& arg = entry[key];
+		TransformStep st = {-1, {0, 0, 0, 0}};
+		if (key == "translate" || key == "scale") {
+			const float3 v = resolveFloat3(arg);
+			st.kind = key == "scale" ? 2 : 0;
+			st.v[0] = v.x; st.v[1] = v.y; st.v[2] = v.z;
+		} else if (key == "rotate") {
+			const float3 axis = resolveFloat3(arg[1]);
+			st.kind = 1;
+			st.v[0] = resolveFloat(arg[0]);
+			st.v[1] = axis.x; st.v[2] = axis.y; st.v[3] = axis.z;
+		}
+		if (st.kind >= 0) steps.push_back(st);
+	}
+	return steps;
+}
+
+// M = M * T for every step in list order (glm's post-multiplying translate / rotate / scale, :94-100).
+glmlite::mat4 composeTransform(const TransformStep* steps, int n) {
+	glmlite::mat4 m;
+	for (int i = 0; i < n; ++i) {
+		const float* v = steps[i].v;
+		switch (steps[i].kind) {
+			case 0: m = glmlite::translate(m, glmlite::vec3{v[0], v[1], v[2]}); break;
+			case 1: m = glmlite::rotate(m, glmlite::radians(v[0]), glmlite::vec3{v[1], v[2], v[3]}); break;
+			case 2: m = glmlite::scale(m, glmlite::vec3{v[0], v[1], v[2]}); break;
+			default: break;
+		}
+	}
+	return m;
+}
+
+static void* sphereSource(const Json::Value& jobj) {
+	const Json::Value& jm = jobj["material"];
+	MaterialFields f;
+	f.type = resolveMatType(jm["type"]);
+	f.Kd = resolveFloat3(jm["Kd"]);
+	f.Ke = resolveFloat3(jm["Ke"]);
+	f.d = resolveFloat(jm["d"]);
+	f.Ni = resolveFloat(jm["Ni"]);
+	f.Ns = resolveFloat(jm["Ns"]);
+	SphereObjInfo* info = (SphereObjInfo*)malloc(sizeof(SphereObjInfo));
+	info->material = makeMaterial(f, -1);
+	info->position = resolveFloat3(jobj["position"]);
+	info->radius = resolveFloat(jobj["radius"]);
+	return info;
+}
+
+static void* meshSource(const Json::Value& jobj) {
+	TriangleMeshObjInfo* info = (TriangleMeshObjInfo*)malloc(sizeof(TriangleMeshObjInfo));
+	snprintf(info->src_filename, sizeof(info->src_filename), "%s", jobj["src"].asString().c_str());
+	const std::vector<TransformStep> steps = readTransformList(jobj["transform"]);
+	info->transform = composeTransform(steps.data(), (int)steps.size());
+	return info;
+}
+
+// reference: src/world_load.cpp:41-115 — at most MAX_OBJECTS_NUM entries of "objects" are looked at, those
+// with "render": false are passed over, any type other than sphere / mesh aborts the load.
 void initWorldObjSources(Scene& scene, const Json::Value& jscene) {
 	world_obj_sources.loadFuncMapping[SphereObj] = loadSphereObj;
 	world_obj_sources.loadFuncMapping[TriangleMeshObj] = loadTriangleMeshObj;
 
-	int num_jobjects = jscene["objects"].isArray() ? (int)jscene["objects"].size() : 0;
-	if (num_jobjects > MAX_OBJECTS_NUM) num_jobjects = MAX_OBJECTS_NUM;
-
-	int obj_idx = 0;
-	for (int i = 0; i < num_jobjects; i++) {
-		const Json::Value& jobj = jscene["objects"][i];
-		bool render = jobj["render"].asBool();
-		if (!render) continue;
-		std::string type = jobj["type"].asString();
-
-		if (type == "sphere") {
-			world_obj_sources.sources[obj_idx].type = SphereObj;
-			Material msphere;
-			msphere.color = resolveFloat3(jobj["material"]["Kd"]);
-			msphere.cuda_texture_obj = -1;
-			msphere.type = resolveMatType(jobj["material"]["type"]);
-			msphere.emittance = resolveFloat3(jobj["material"]["Ke"]);
-			msphere.reflect_factor = resolveFloat(jobj["material"]["d"]);
-			msphere.refract_index = resolveFloat(jobj["material"]["Ni"]);
-			msphere.sharpness = clampf(resolveFloat(jobj["material"]["Ns"]) / 1000.0f, 0.0f, 1.0f);
-
-			SphereObjInfo* sinfo = (SphereObjInfo*)malloc(sizeof(SphereObjInfo));
-			sinfo->material = msphere;
-			sinfo->position = resolveFloat3(jobj["position"]);
-			sinfo->radius = resolveFloat(jobj["radius"]);
-			world_obj_sources.sources[obj_idx].worldObjectInfo = sinfo;
-			obj_idx++;
-		} else if (type == "mesh") {
-			world_obj_sources.sources[obj_idx].type = TriangleMeshObj;
-			TriangleMeshObjInfo* minfo = (TriangleMeshObjInfo*)malloc(sizeof(TriangleMeshObjInfo));
-			std::string src = jobj["src"].asString();
-			strncpy(minfo->src_filename, src.c_str(), sizeof(minfo->src_filename) - 1);
-			minfo->src_filename[sizeof(minfo->src_filename) - 1] = 0;
-
-			glmlite::mat4 transform;
-			if (jobj["transform"].isArray()) {
-				for (unsigned t = 0; t < jobj["transform"].size(); t++) {
-					const Json::Value& jtrans = jobj["transform"][t];
-					if (!jtrans.isObject() || jtrans.size() != 1) continue;
-					std::string trans_type = jtrans.getMemberNames()[0];
-					if (trans_type == "translate")
-						transform = glmlite::translate(transform, resolveGlmVec3(jtrans[trans_type]));
-					else if (trans_type == "rotate")
-						transform = glmlite::rotate(transform, glmlite::radians(resolveFloat(jtrans[trans_type][0])),
-						                            resolveGlmVec3(jtrans[trans_type][1]));
-					else if (trans_type == "scale")
-						transform = glmlite::scale(transform, resolveGlmVec3(jtrans[trans_type]));
-				}
-			}
-			minfo->transform = transform;
-			world_obj_sources.sources[obj_idx].worldObjectInfo = minfo;
-			obj_idx++;
-		} else {
-			world_obj_sources.num_objects = obj_idx;
+	const Json::Value& jobjects = jscene["objects"];
+	const int listed = jobjects.isArray() ? std::min((int)jobjects.size(), MAX_OBJECTS_NUM) : 0;
+	int kept = 0;
+	for (int i = 0; i < listed; ++i) {
+		const Json::Value& jobj = jobjects[i];
+		if (!jobj["render"].asBool()) continue;
+		const std::string type = jobj["type"].asString();
+		WorldObjectDescription& slot = world_obj_sources.sources[kept];
+		if (type == "sphere") { slot.type = SphereObj; slot.worldObjectInfo = sphereSource(jobj); }
+		else if (type == "mesh") { slot.type = TriangleMeshObj; slot.worldObjectInfo = meshSource(jobj); }
+		else {
+			world_obj_sources.num_objects = kept;
 			freeWorldObjects();
 			throw scene_file_error("Unknown object type, supported types: mesh/sphere");
 		}
+		++kept;
 	}
-	scene.num_wobjects = world_obj_sources.num_objects = obj_idx;
+	scene.num_wobjects = world_obj_sources.num_objects = kept;
 }
 
 static void freeWorldObjSources() {
@@ -157,21 +204,18 @@ int loadTexture(const std::string src_path) {
 	std::string err;
 	if (!loadImageFloat(path, width, height, channels, img, err)) return -1;
 
+	// file row r becomes texture row height-1-r; grey -> (g, g, g, 1), grey+alpha -> (g, g, g, a), RGB -> alpha 1
 	HostTexture tex;
 	tex.width = width;
 	tex.height = height;
 	tex.rgba.resize((size_t)width * height * 4);
-	for (int row = 0; row < height; row++) {
-		for (int col = 0; col < width; col++) {
-			size_t index = (size_t)channels * ((size_t)row * width + col);
-			float rgba[4] = {0.0f, 0.0f, 0.0f, 1.0f};
-			for (int channel = 0; channel < channels; channel++) rgba[channel] = img[index + channel];
-			size_t host_index = ((size_t)(height - row - 1) * width + col) * 4;
-			float* o = &tex.rgba[host_index];
-			if (channels < 2) { o[0] = rgba[0]; o[1] = rgba[0]; o[2] = rgba[0]; o[3] = rgba[3]; }
-			else if (channels < 3) { o[0] = rgba[0]; o[1] = rgba[0]; o[2] = rgba[0]; o[3] = rgba[1]; }
-			else { o[0] = rgba[0]; o[1] = rgba[1]; o[2] = rgba[2]; o[3] = rgba[3]; }
-		}
+	static const int pick[4][4] = {{0, 0, 0, -1}, {0, 0, 0, 1}, {0, 1, 2, -1}, {0, 1, 2, 3}};
+	const int* from = pick[channels - 1];
+	for (int row = 0; row < height; ++row) {
+		const float* src = &img[(size_t)channels * width * row];
+		float* dst = &tex.rgba[(size_t)4 * width * (height - 1 - row)];
+		for (int col = 0; col < width; ++col, src += channels, dst += 4)
+			for (int k = 0; k < 4; ++k) dst[k] = from[k] < 0 ? 1.0f : src[from[k]];
 	}
 	host_textures.push_back(tex);
 	int idx = (int)host_textures.size() - 1;
@@ -194,15 +238,15 @@ static Material* loadMaterialsToHost(const ObjScene& oscene) {
 
 		REPORT(info("  Loading material[%d]: name: %s, type: %s", i, sname.c_str(), mat_type.c_str()));
 
-		mat_ptr[i].cuda_texture_obj = -1;
+		int texture = -1;
 		const std::string* texture_path = NULL;
 		if (!material.map_ambient.empty()) texture_path = &material.map_ambient;
 		else if (!material.map_diffuse.empty()) texture_path = &material.map_diffuse;
 		else if (!material.map_emissive.empty()) texture_path = &material.map_emissive;
 		if (texture_path) {
 			REPORT(info("    Loading texture: %s", texture_path->c_str()));
-			mat_ptr[i].cuda_texture_obj = loadTexture(*texture_path);
-			if (mat_ptr[i].cuda_texture_obj < 0) {
+			texture = loadTexture(*texture_path);
+			if (texture < 0) {
 				// printed once per file and process: lp560.mtl names 19 absent TGAs from 41 materials
 				static std::map<std::string, int>* warned = new std::map<std::string, int>();
 				if ((*warned)[*texture_path]++ == 0) printf("    Warning: texture load failed: %s\n", texture_path->c_str());
@@ -214,13 +258,14 @@ static Material* loadMaterialsToHost(const ObjScene& oscene) {
 
 		// reference :235,269: assimp hands back 4x the MTL's Ns and the loader divides by 4 before
 		// the /1000 clamp; net effect sharpness = clamp(Ns_file / 1000, 0, 1).
-		float Ns = material.Ns;
-		mat_ptr[i].type = resolveMatType(mat_type);
-		mat_ptr[i].color = make_float3(material.Kd[0], material.Kd[1], material.Kd[2]);
-		mat_ptr[i].emittance = make_float3(material.Ke[0], material.Ke[1], material.Ke[2]);
-		mat_ptr[i].reflect_factor = material.d;
-		mat_ptr[i].refract_index = material.Ni;
-		mat_ptr[i].sharpness = clampf(Ns / 1000.0f, 0.0f, 1.0f);
+		MaterialFields f;
+		f.type = resolveMatType(mat_type);
+		f.Kd = make_float3(material.Kd[0], material.Kd[1], material.Kd[2]);
+		f.Ke = make_float3(material.Ke[0], material.Ke[1], material.Ke[2]);
+		f.d = material.d;
+		f.Ni = material.Ni;
+		f.Ns = material.Ns;
+		mat_ptr[i] = makeMaterial(f, texture);
 	}
 	return mat_ptr;
 }
@@ -264,21 +309,21 @@ static Triangle* loadTriangles(const ObjScene& oscene, const glmlite::mat4& tran
 	return tr;
 }
 
-// reference: src/world_load.cpp:385-410
+// reference: src/world_load.cpp:385-410 — a sphere object owns one material and a (radius, centre) record;
+// both live in one host block here (the reference makes two device allocations).
 bool loadSphereObj(void* objInfo, WorldObject& result) {
-	SphereObjInfo* info = (SphereObjInfo*)objInfo;
-	REPORT(info("Loading Sphere Object: r=%f, pos=[%f,%f,%f]", info->radius, info->position.x, info->position.y, info->position.z));
-	SphereGeometryData* gptr = (SphereGeometryData*)malloc(sizeof(SphereGeometryData));
-	gptr->position = info->position;
-	gptr->radius = info->radius;
-	Material* mat = (Material*)malloc(sizeof(Material));
-	*mat = info->material;
-	host_mem_ptrs.push_back(mat);
-	host_mem_ptrs.push_back(gptr);
+	const SphereObjInfo& src = *(const SphereObjInfo*)objInfo;
+	REPORT(info("Loading Sphere Object: r=%f, pos=[%f,%f,%f]", src.radius, src.position.x, src.position.y, src.position.z));
+	struct Block { Material material; SphereGeometryData geom; };
+	Block* blk = (Block*)malloc(sizeof(Block));
+	blk->material = src.material;
+	blk->geom.radius = src.radius;
+	blk->geom.position = src.position;
+	host_mem_ptrs.push_back(blk);
 	result.type = SphereObj;
-	result.materials = mat;
+	result.materials = &blk->material;
 	result.num_materials = 1;
-	result.geometry_data = gptr;
+	result.geometry_data = &blk->geom;
 	return true;
 }
 

@@ -52,6 +52,11 @@ typedef struct {
 
 extern WorldObjectsSources world_obj_sources;
 
+// one entry of a mesh's "transform" list: kind 0 translate(v0,v1,v2), 1 rotate(v0 degrees about (v1,v2,v3)),
+// 2 scale(v0,v1,v2); composeTransform applies them in order as M = M * T (reference: src/world_load.cpp:84-101)
+typedef struct { int kind; float v[4]; } TransformStep;
+glmlite::mat4 composeTransform(const TransformStep* steps, int n);
+
 // ---- headless additions (no reference counterpart) -------------------------
 // Directory that relative asset paths ("./scenes/...", ".\textures\...") are
 // resolved against. The reference resolves them against the process CWD; the

@@ -7,7 +7,9 @@ Two files, two kinds of provenance:
 
 ref_pins.json        outputs of the REFERENCE's own code, compiled unchanged from /root/reference by
                      oracle/Makefile (target ref: utility.cpp, camera.cpp, jsonResolve.cpp, jsoncpp.cpp):
-                     fmedian, Camera::init / rotate / move, resolveFloat3 / resolveFloat / resolveMatType.
+                     fmedian, Camera::init / rotate / move, resolveFloat3 / resolveFloat / resolveMatType;
+                     external/include/stb/stb_image.h (stbi_loadf of every shipped texture and of the synthetic
+                     files of make_images.py) and external/include/glm (mesh transform chains).
                      These pin the oracle and the product's host code without needing the reference at
                      test time (it does not travel to the GPU box).
 oracle_vectors.npz   outputs of the CPU oracle (oracle/pt_oracle.cpp) for the device path: KD-tree
@@ -90,6 +92,19 @@ def make_ref_pins():
     hashes = np.array([R.ref_wang_hash(int(x)) for x in seeds], np.uint32)
     np.savez_compressed(os.path.join(HERE, "ref_vec3.npz"), a=a, b=b, s=s, out_bits=bits3, wang_in=seeds, wang_out=hashes)
     out["vec3"] = {"file": "ref_vec3.npz", "cases": int(len(a)), "sha1_of_outputs": hashlib.sha1(bits3.tobytes()).hexdigest()}
+    # texture decode: what the reference's own stb_image.h (stbi_loadf, req_comp 0) makes of every shipped
+    # texture and of the synthetic fixtures of make_images.py; sha1 over the float32 array
+    out["images"] = {}
+    for rel in orc.image_files():
+        r = orc.decode_with(R.ref_stbi_loadf, R.ref_stbi_free, rel)
+        out["images"][rel] = {"fails": True} if r is None else {"w": r[0], "h": r[1], "channels": r[2], "sha1": hashlib.sha1(r[3].tobytes()).hexdigest()}
+    # mesh transforms through the reference's glm (translate / rotate / scale chains, transpose(inverse(M)), M * vec4)
+    pts = np.random.default_rng(22).normal(size=(64, 3)).astype(np.float32)
+    out["transforms"] = []
+    for ops in orc.transform_cases():
+        m, nm, o1, o2 = orc.transform_eval(R.ref_glm_transform, R.ref_glm_apply, ops, pts)
+        out["transforms"].append({"m16_bits": m.tolist(), "normal16_bits": nm.tolist(),
+                                  "sha1_points": hashlib.sha1(o1.tobytes() + o2.tobytes()).hexdigest()})
     with open(os.path.join(HERE, "ref_pins.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print("ref_pins.json:", {k: len(v) for k, v in out.items() if not isinstance(v, str)})

@@ -65,8 +65,100 @@ def ref():
             R.ref_vec3_ops.argtypes = [fp, fp, C.c_float, fp]
             R.ref_wang_hash.argtypes = [C.c_uint32]
             R.ref_wang_hash.restype = C.c_uint32
+        if hasattr(R, "ref_stbi_loadf"):
+            ip = C.POINTER(C.c_int)
+            R.ref_stbi_loadf.argtypes = [C.c_char_p, ip, ip, ip]
+            R.ref_stbi_loadf.restype = fp
+            R.ref_stbi_free.argtypes = [C.c_void_p]
+            R.ref_stbi_failure.restype = C.c_char_p
+            R.ref_glm_transform.argtypes = [fp, C.c_int, fp, fp]
+            R.ref_glm_apply.argtypes = [fp, fp, C.c_int, fp]
         _ref = R
     return _ref
+
+
+def image_files():
+    """The shipped textures and the synthetic decoder fixtures (tests/golden/img, made by make_images.py),
+    as paths relative to the repo root."""
+    out = []
+    for sub in ("textures", "textures/lp560", "tests/golden/img"):
+        d = os.path.join(ROOT, sub)
+        out += [f"{sub}/{f}" for f in sorted(os.listdir(d)) if f.lower().endswith((".png", ".jpg", ".tga"))]
+    return out
+
+
+def decode_with(load, free, rel):
+    """(w, h, channels, float32 array) or None; `load` is ref_stbi_loadf or a wrapper of pth_load_image_float."""
+    w, h, c = C.c_int(), C.c_int(), C.c_int()
+    p = load(os.path.join(ROOT, rel).encode(), C.byref(w), C.byref(h), C.byref(c))
+    if not p:
+        return None
+    a = np.ctypeslib.as_array(p, (h.value * w.value * c.value,)).copy()
+    free(p)
+    return w.value, h.value, c.value, a
+
+
+def product_image_loader(H):
+    fp = C.POINTER(C.c_float)
+    ip = C.POINTER(C.c_int)
+    H.pth_load_image_float.argtypes = [C.c_char_p, ip, ip, ip, C.POINTER(fp)]
+
+    def load(path, w, h, c):
+        q = fp()
+        return q if H.pth_load_image_float(path, w, h, c, C.byref(q)) == 0 else None
+    return load, H.pth_free
+
+
+def transform_cases():
+    """Transform lists as (n, 5) float32 records (kind 0 translate / 1 rotate degrees + axis / 2 scale): those of
+    the shipped scene files, then seeded random ones (degenerate scales and long chains included)."""
+    import glob
+    import json
+    cases = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "scenes", "*.json"))):
+        for ob in json.load(open(f)).get("objects", []):
+            ops = []
+            for t in ob.get("transform", []) if isinstance(ob.get("transform"), list) else []:
+                if not isinstance(t, dict) or len(t) != 1:
+                    continue
+                (k, v), = t.items()
+
+                def f3(a):  # resolveFloat3: 3-arrays, 1-arrays broadcast, anything else 0
+                    return list(a) if isinstance(a, list) and len(a) == 3 else [a[0]] * 3 if isinstance(a, list) and len(a) == 1 else [0, 0, 0]
+                if k == "translate":
+                    ops.append([0] + f3(v) + [0])
+                elif k == "scale":
+                    ops.append([2] + f3(v) + [0])
+                elif k == "rotate":
+                    ops.append([1, v[0]] + f3(v[1]))
+            if ops:
+                cases.append(np.array(ops, np.float32))
+    rng = np.random.default_rng(21)
+    for i in range(160):
+        n = int(rng.integers(1, 7))
+        ops = np.zeros((n, 5), np.float32)
+        for r in ops:
+            r[0] = rng.integers(0, 3)
+            r[1:] = rng.normal(size=4) * (10.0 ** rng.integers(-2, 3))
+            if r[0] == 1:
+                r[1] = rng.uniform(-720, 720)
+            if r[0] == 2 and i % 9 == 0:
+                r[1:4] = np.abs(r[1:4]) + np.float32(0.01)
+        cases.append(ops)
+    cases.append(np.zeros((0, 5), np.float32))
+    return cases
+
+
+def transform_eval(compose, apply_, ops, pts):
+    """(m16 bits, normal16 bits, transformed points bits, transformed-by-normal-matrix bits) through either the
+    reference's glm (ref_glm_*) or the product's loader (pth_transform_*)."""
+    ops = np.ascontiguousarray(ops, np.float32)
+    m = np.zeros(16, np.float32); nm = np.zeros(16, np.float32)
+    compose(fptr(ops) if len(ops) else fptr(np.zeros(5, np.float32)), len(ops), fptr(m), fptr(nm))
+    o1 = np.zeros((len(pts), 4), np.float32); o2 = np.zeros((len(pts), 4), np.float32)
+    apply_(fptr(m), fptr(pts), len(pts), fptr(o1))
+    apply_(fptr(nm), fptr(pts), len(pts), fptr(o2))
+    return m.view(np.uint32), nm.view(np.uint32), o1.view(np.uint32), o2.view(np.uint32)
 
 
 def fptr(a):

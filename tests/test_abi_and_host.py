@@ -140,31 +140,6 @@ def test_unknown_object_type_and_bad_json_fail(pt, tmp_path):
     assert H.pth_scene_desc().contents.num_objects == 0
 
 
-def test_texture_decode_against_pil(pt):
-    from PIL import Image
-    H = pt.host()
-    for rel, tol in (("textures/floor.png", 0), ("textures/sea_cbm.jpg", 3)):
-        path = os.path.join(ROOT, rel)
-        w, h, ch = C.c_int(), C.c_int(), C.c_int()
-        px = C.POINTER(C.c_float)()
-        assert H.pth_load_image_float(path.encode(), C.byref(w), C.byref(h), C.byref(ch), C.byref(px)) == 0
-        im = Image.open(path)
-        assert (w.value, h.value) == im.size and ch.value == len(im.getbands())
-        ref8 = np.asarray(im, dtype=np.uint8).reshape(h.value, w.value, ch.value)
-        got = np.ctypeslib.as_array(px, shape=(h.value, w.value, ch.value))
-        # invert stbi_loadf's rule: colour = pow(v/255, 2.2), alpha = v/255
-        got8 = np.empty_like(ref8)
-        ncol = ch.value if ch.value % 2 else ch.value - 1
-        got8[..., :ncol] = np.rint(255.0 * np.power(got[..., :ncol].astype(np.float64), 1 / 2.2))
-        if ncol < ch.value:
-            got8[..., ncol:] = np.rint(255.0 * got[..., ncol:])
-        diff = np.abs(got8.astype(int) - ref8.astype(int))
-        assert diff.max() <= tol, (rel, diff.max())
-        if tol:
-            assert diff.mean() < 0.6
-        H.pth_free(px)
-
-
 def test_png_writer_roundtrip(pt, tmp_path):
     from PIL import Image
     rng = np.random.default_rng(0)

@@ -116,3 +116,41 @@ def test_float3_helpers_and_wang_hash_pinned(ref, orc):
     assert np.isfinite(r.view(np.float32)).mean() > 0.9
     for seed in list(range(64)) + [12345, 0x7fffffff, 0x80000000, 0xffffffff]:
         assert ref.ref_wang_hash(seed) == orc.lib().orc_wang_hash(seed)
+
+
+def test_texture_decode_equals_reference_stb(ref, orc, pt):
+    """a16: pth_load_image_float (host/image_io.cpp) against stbi_loadf of the REFERENCE's own
+    external/include/stb/stb_image.h (compiled unchanged into oracle/_ref, oracle/ref_stb.cpp), tolerance 0: every
+    shipped texture (PNG, baseline JPEG with restart intervals, 29 TGAs) and the 148 synthetic files of
+    tests/golden/make_images.py (subsampled / progressive / grey / CMYK JPEGs, every PNG colour type x depth x
+    Adam7 + tRNS + palettes, raw / RLE / colour-mapped / 15-16-bit TGAs, truncated and bit-flipped files, which must
+    fail or half-decode alike)."""
+    load, free = orc.product_image_loader(pt.host())
+    files = orc.image_files()
+    assert len(files) > 170
+    for rel in files:
+        r = orc.decode_with(ref.ref_stbi_loadf, ref.ref_stbi_free, rel)
+        g = orc.decode_with(load, free, rel)
+        assert (r is None) == (g is None), rel
+        if r is not None:
+            assert r[:3] == g[:3], rel
+            assert np.array_equal(r[3].view(np.uint32), g[3].view(np.uint32)), rel
+
+
+def test_mesh_transforms_equal_reference_glm(ref, orc, pt):
+    """a21: the loader's transform chains (world_load.cpp composeTransform on host/glmlite.h), transpose(inverse(M))
+    and M * vec4 against the reference's vendored glm 0.9.8.5 (oracle/ref_glm.cpp), bit for bit, on the transform
+    lists of every shipped scene and 160 random chains."""
+    H = pt.host()
+    fp = C.POINTER(C.c_float)
+    H.pth_transform_compose.argtypes = [fp, C.c_int, fp, fp]
+    H.pth_transform_apply.argtypes = [fp, fp, C.c_int, fp]
+    pts = np.random.default_rng(22).normal(size=(64, 3)).astype(np.float32)
+    cases = orc.transform_cases()
+    assert len(cases) > 170
+    for i, ops in enumerate(cases):
+        r = orc.transform_eval(ref.ref_glm_transform, ref.ref_glm_apply, ops, pts)
+        g = orc.transform_eval(H.pth_transform_compose, H.pth_transform_apply, ops, pts)
+        for a, b in zip(r, g):
+            fa, fb = a.view(np.float32), b.view(np.float32)
+            assert ((a == b) | (np.isnan(fa) & np.isnan(fb))).all(), (i, ops)
