@@ -157,6 +157,87 @@ def test_fragile_hits_at_grazing_incidence_equal_the_oracle(pt, orc, ctx):
         _tune(pt, ctx, b"trav_variant", -1)
 
 
+def _load_grazing_tool():
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("grazing_stress", os.path.join(os.path.dirname(__file__), "..", "tools", "grazing_stress.py"))
+    gs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gs)
+    return gs
+
+
+# What the DEFAULT traversal (variant 0, wide tree + distance culling with a margin) is known not to reproduce: hits the
+# reference's triangle test accepts out of pure rounding noise (|det| ~ 1e-7 |e1||e2|: t, u, v carry no digits) on a triangle
+# whose boxes lie more than the culling margin behind a well-conditioned hit. 2 000 000 adversarial grazing rays per scene
+# hold 1 such ray on the car and 2 on the soup. The ceilings below fence that regime: the exact kernel
+# (variant 15, what PTX_TRAV_VARIANT=15 / ptx_ctx_tune selects) must differ in NONE, the default in at most these, and every ray it
+# differs in must be such a noise hit of the oracle (its t more than 1e-3 in front of the triangle it names).
+GRAZING_CEILING = {"lamborghini": 2, "soup": 3}
+
+
+@pytest.mark.parametrize("which", ["lamborghini", "soup"])
+def test_two_million_grazing_rays_exact_kernel_equals_oracle_and_default_stays_under_its_ceiling(pt, orc, ctx, tmp_path, which):
+    gs = _load_grazing_tool()
+    rng = np.random.default_rng(5)
+    if which == "soup":
+        gs.write_soup(str(tmp_path / "soup.obj"), 20000, rng)
+        (tmp_path / "s.json").write_text(
+            '{"camera": {"pixelWidth": 64, "pixelHeight": 48, "direction": [0,0,-1], "up": [0,1,0], "position": [0,0,20],'
+            ' "screenDist": 1.5, "screenHeight": 2}, "objects": [{"type": "mesh", "render": true, "src": "%s"}]}' % (tmp_path / "soup.obj"))
+        name = str(tmp_path / "s.json")
+    else:
+        name = "lamborghini"
+    desc, cam = pt.load_scene(name, 64, 48)
+    scene = pt.host().pth_scene_device()
+    d = desc.contents
+    obj = max(range(d.num_objects), key=lambda i: d.objects[i].num_nodes)
+    o, dd, tgt = gs.grazing_rays(desc, obj, 2000000, rng)
+    ho = orc.trace(desc, o, dd, obj)
+    assert (ho["object"] == obj).sum() > 1500000
+    tris = np.ctypeslib.as_array(C.cast(d.triangles, C.POINTER(pt.PtxTriangle * d.num_triangles)).contents)
+    tris = tris[d.objects[obj].first_triangle: d.objects[obj].first_triangle + d.objects[obj].num_triangles]
+    try:
+        differ = {}
+        for variant in (15, 0):
+            _tune(pt, ctx, b"trav_variant", variant)
+            hg = gpuops.trace_queued(ctx, scene, o, dd, obj)
+            bad = np.zeros(len(o), bool)
+            for k in ("object", "prim", "t_bits", "bary"):
+                bad |= (ho[k] != hg[k]).reshape(len(o), -1).any(axis=1)
+            differ[variant] = np.nonzero(bad)[0]
+        assert len(differ[15]) == 0, f"exact kernel differs from the oracle in {len(differ[15])} rays, first {differ[15][:5]}"
+        print(f"\n{which}: default traversal differs from the oracle in {len(differ[0])} of {len(o)} grazing rays: {differ[0].tolist()}")
+        assert len(differ[0]) <= GRAZING_CEILING[which], f"default traversal: {len(differ[0])} rays differ (ceiling {GRAZING_CEILING[which]}): {differ[0][:10]}"
+        for i in differ[0]:
+            t = tris[int(ho["prim"][i])]
+            a, e1, e2 = (t[k].astype(np.float64) for k in ("a", "e1", "e2"))
+            dv, ov = dd[i].astype(np.float64), o[i].astype(np.float64)
+            t64 = (e2 @ np.cross(ov - a, e1)) / (e1 @ np.cross(dv, e2))
+            t32 = float(ho["t_bits"][i:i + 1].view(np.float32)[0])
+            assert abs(t64 - t32) > 1e-3, f"ray {i}: the oracle's hit is well conditioned (t {t32} vs {t64} in double) and the default traversal misses it"
+    finally:
+        _tune(pt, ctx, b"trav_variant", -1)
+
+
+def test_production_rays_default_and_exact_traversal_accumulate_identically(pt, ctx):
+    """The production distribution: the headline frame (1920x1080, textures on, 5 bounces), 256 samples per pixel = 1.1e9
+    path segments, 340 M of them traversals of the car's tree, through the default traversal and through the exact kernel
+    alone (variant 15 = the reference's visiting order): the accumulation buffers are bit-identical. (The same comparison at
+    1000 spp, 4.4e9 segments, is tools/production_parity.py; its result is recorded in DESIGN.md 3.2.)"""
+    desc, cam = pt.load_scene("lamborghini", width=1920, height=1080, textures=1)
+    scene = pt.host().pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    try:
+        _tune(pt, ctx, b"trav_variant", 15)
+        ref, st_e = gpuops.render(ctx, scene, cam, 0, 256, 7, batch=128)
+        _tune(pt, ctx, b"trav_variant", 0)
+        acc, st_w = gpuops.render(ctx, scene, cam, 0, 256, 7, batch=128)
+        assert st_e.rays == st_w.rays > 1.0e9
+        bad = np.nonzero((ref.view(np.uint32) != acc.view(np.uint32)).any(axis=1))[0]
+        assert len(bad) == 0, f"{len(bad)} pixels differ, first {bad[:5]}"
+    finally:
+        _tune(pt, ctx, b"trav_variant", -1)
+
+
 @pytest.mark.parametrize("seed", list(range(11, 27)))
 def test_random_soups_render_like_the_oracle(pt, orc, ctx, tmp_path, seed):
     """Fuzz: triangle soups of random size, density and triangle shape (needles and slivers included), a random
