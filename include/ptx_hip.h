@@ -239,14 +239,26 @@ int ptx_wavefront_counts(PtxCtx* ctx, int max_bounces, int32_t* live_out, int32_
  * summed durations / launch counts since enabling and clears them. No reference counterpart. */
 int ptx_profile_enable(PtxCtx* ctx, int enable);
 int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches, float* segment_ms, int32_t* segment_launches);
-/* Scheduling knobs of the render path (no reference counterpart; results do not depend on them, the parity
- * tests run the variants against each other): key = "trav_variant" (traversal kernel variant, see
- * ptx_hip.hip), "trav_blocks" (persistent blocks per CU), "wf_batch" (samples per wavefront pass, 1..256, default 128),
- * "megakernel" (1 = one-lane-per-pixel kernel instead of the wavefront pipeline), "grp_pad_ppm" (padding
- * of the boxes around the groups of eight triangles inside the leaves, in parts per million of the mesh
- * diagonal, on top of 5e-5; read by the NEXT ptx_scene_upload). Defaults come from the environment
- * (PTX_TRAV_VARIANT, PTX_TRAV_BLOCKS, PTX_WF_BATCH, PTX_MEGAKERNEL, PTX_GRP_PAD_PPM) at ptx_ctx_create.
- * value < 0 restores that default. */
+/* Scheduling knobs of the render path (no reference counterpart). key =
+ *   "trav_variant"    traversal kernel: 0 (default) = the wide traversal (pt_wide.h) + the exact kernel over its retry queue,
+ *                     14 = the same with the wide kernel's own counting twin, 15 = the EXACT kernel alone (the reference's
+ *                     node-by-node visiting order, src/intersect.cuh:119-212)
+ *   "wide_margin_ppm" margin of the wide traversal's distance culling, parts per million (default 10000 = 1 %)
+ *   "wide_scap"       stack entries per lane of the wide traversal (default 10; rays that need more go to the exact kernel)
+ *   "wide_cfg"        A/B configurations of the wide kernel (waves per SIMD, turn / drain thresholds)
+ *   "grp_mode", "grp_pad_ppm"  how leaf triangles are cut into groups of eight and how far their boxes are padded (parts per
+ *                     million of the mesh diagonal, on top of 5e-5); read by the NEXT ptx_scene_upload
+ *   "seg_lds_tables"  material / texture-descriptor tables of the segment kernel in LDS (default 1)
+ *   "trav_blocks"     persistent workgroups per CU;  "wf_batch"  samples per wavefront pass (1..256, default 128)
+ *   "megakernel"      1 = one-lane-per-pixel kernel instead of the wavefront pipeline
+ * WHAT CAN CHANGE A RESULT: nothing but "trav_variant" 0 / 14 together with "wide_margin_ppm", and only on rays at grazing
+ * incidence where the reference's triangle test accepts a hit out of rounding noise (|det| ~ 1e-7 |e1||e2|) on a triangle
+ * whose boxes lie more than the margin behind a well-conditioned hit: measured 1 ray in 2 000 000 adversarial grazing rays
+ * on the headline mesh, 0 pixels of the headline frame at 1000 spp (tests/test_gpu_wide.py). "trav_variant"
+ * 15 reproduces the reference on those too. Every other knob only reschedules work; the parity tests run the variants
+ * against each other. Defaults come from the environment (PTX_TRAV_VARIANT, PTX_WIDE_MARGIN_PPM, PTX_WIDE_SCAP,
+ * PTX_WIDE_CFG, PTX_GRP_MODE, PTX_GRP_PAD_PPM, PTX_SEG_LDS_TABLES, PTX_TRAV_BLOCKS, PTX_WF_BATCH, PTX_MEGAKERNEL) at
+ * ptx_ctx_create; value < 0 restores that default. */
 int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value);
 /* HIP-event timer on the context's stream (for bench.py's roofline leg). */
 int ptx_timer_begin(PtxCtx* ctx);

@@ -65,6 +65,10 @@ struct WfParams {
 	uint32_t k0, k1;
 	int bounce, is_last;
 	int num_big;
+	// one state set and one queue segment per bounce (pt_segloop.h): set b = s0..s3 + b * set_stride, queue (b, k) =
+	// queue[k] + b * queue_stride; the traversal kernels and the per-bounce segment kernel get pointers the host has offset already
+	size_t set_stride, queue_stride;
+	int max_bounces;
 };
 
 #define WF_CNT(wp, b, k) ((wp).counters[(b) * (1 + PT_MAX_BIG) + (k)])
@@ -73,7 +77,7 @@ struct WfParams {
 // the same pair for the retry queue of (bounce, queue): its length and the next unclaimed entry
 #define WF_RCNT(wp, b, k) ((wp).counters[2 * (PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) + (b) * (1 + PT_MAX_BIG) + (k)])
 #define WF_RCUR(wp, b, k) ((wp).counters[3 * (PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) + (b) * (1 + PT_MAX_BIG) + (k)])
-#define WF_COUNTER_INTS (4 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG))
+#define WF_COUNTER_INTS (4 * (size_t)(PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) + (PT_WF_MAX_BOUNCES + 1))   /* + the segment launches' input cursors (pt_segloop.h) */
 
 // Queue feed of a persistent traversal wave. A wave claims CHUNK consecutive queue entries at a time
 // with one atomic (wave-uniform state: next/hi/exhausted), so every wave keeps all its lanes fed until

@@ -4,6 +4,7 @@
 // entry point returns an error.
 #include "pt_unified.h"
 #include "pt_wide.h"
+#include "pt_segloop.h"
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -53,13 +54,12 @@ struct PtxCtx {
 	// wavefront pipeline buffers (allocated on first use, grown on demand); wf.s0..s3 and wf_b[0..3] are the two
 	// sets of compacted path state (pt_wavefront.h), used in turn from bounce to bounce
 	WfParams wf;
-	float4* wf_b[4];
-	size_t wf_paths, wf_rad;   // capacities (paths, rad entries)
-	int wf_queues;
+	size_t wf_paths, wf_rad;   // capacities (paths per state set, rad entries)
+	int wf_queues, wf_sets;    // queues and state sets allocated (wf.s0..s3 hold wf_sets sets of wf_paths records each, wf.queue[k] as many segments)
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
-	int wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm;
+	int wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -124,7 +124,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode;
 	bool force_megakernel;
 };
 
@@ -146,6 +146,8 @@ static Tuning tuning_defaults() {
 	// wide traversal (pt_wide.h): A/B configuration of the kernel and the most stack entries a lane may hold
 	t.grp_mode = clampi(env_int("PTX_GRP_MODE", 1), 0, 1);   // how a leaf's triangles are cut into groups of eight; read at scene upload
 	t.seg_lds_tables = env_int("PTX_SEG_LDS_TABLES", 1) != 0;
+	// segment kernel: 1 = bounce loop inside the launch (pt_segloop.h), 0 = one bounce per launch (wf_segment_kernel)
+	t.seg_mode = clampi(env_int("PTX_SEG_MODE", 1), 0, 1);
 	// margin of the wide traversal's distance culling, relative to the best t (and absolute), in parts per million (pt_wide.h)
 	t.wide_margin_ppm = clampi(env_int("PTX_WIDE_MARGIN_PPM", 10000), 0, 1000000);
 	t.wide_cfg = env_int("PTX_WIDE_CFG", 0);
@@ -164,6 +166,7 @@ static void tune_defaults(PtxCtx* c) {
 	c->grp_mode = t.grp_mode;
 	c->wide_margin_ppm = t.wide_margin_ppm;
 	c->seg_lds_tables = t.seg_lds_tables;
+	c->seg_mode = t.seg_mode;
 	c->wide_scap = t.wide_scap;
 }
 
@@ -177,6 +180,7 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "grp_pad_ppm")) ctx->grp_pad_ppm = value < 0 ? d.grp_pad_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "grp_mode")) ctx->grp_mode = value < 0 ? d.grp_mode : clampi(value, 0, 1);
 	else if (!strcmp(key, "seg_lds_tables")) ctx->seg_lds_tables = value < 0 ? d.seg_lds_tables : (value != 0);
+	else if (!strcmp(key, "seg_mode")) ctx->seg_mode = value < 0 ? d.seg_mode : clampi(value, 0, 1);
 	else if (!strcmp(key, "wide_margin_ppm")) ctx->wide_margin_ppm = value < 0 ? d.wide_margin_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "wide_cfg")) ctx->wide_cfg = value < 0 ? d.wide_cfg : value;
 	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
@@ -212,37 +216,39 @@ extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 extern "C" int ptx_render_cleanup(PtxCtx* ctx);
 
 static void wf_free(PtxCtx* c) {
-	void* ptrs[] = {c->wf.s0, c->wf.s1, c->wf.s2, c->wf.s3, c->wf_b[0], c->wf_b[1], c->wf_b[2], c->wf_b[3], c->wf.rad, c->wf.counters, c->wf.retry};
+	void* ptrs[] = {c->wf.s0, c->wf.s1, c->wf.s2, c->wf.s3, c->wf.rad, c->wf.counters, c->wf.retry};
 	for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i)
 		if (ptrs[i]) hipFree(ptrs[i]);
 	for (int k = 0; k < PT_MAX_BIG; ++k)
 		if (c->wf.queue[k]) hipFree(c->wf.queue[k]);
 	memset(&c->wf, 0, sizeof(c->wf));
-	memset(c->wf_b, 0, sizeof(c->wf_b));
 	c->wf_paths = c->wf_rad = 0;
-	c->wf_queues = 0;
+	c->wf_queues = c->wf_sets = 0;
 }
 
-// Path-state, live-list, queue and radiance buffers for `paths` paths / `rad` radiance slots / `queues` queues.
-static int wf_ensure(PtxCtx* c, size_t paths, size_t rad, int queues) {
-	if (paths <= c->wf_paths && rad <= c->wf_rad && queues <= c->wf_queues) return PTX_OK;
+// Path-state sets, queues and radiance buffers: `sets` state sets of `paths` records (64 B each, four planes), `queues`
+// queues of sets x paths entries, `rad` radiance slots.
+static int wf_ensure(PtxCtx* c, size_t paths, size_t rad, int queues, int sets) {
+	if (paths <= c->wf_paths && rad <= c->wf_rad && queues <= c->wf_queues && sets <= c->wf_sets) return PTX_OK;
 	HIP_TRY(hipStreamSynchronize(c->stream));
 	if (paths < c->wf_paths) paths = c->wf_paths;
 	if (rad < c->wf_rad) rad = c->wf_rad;
 	if (queues < c->wf_queues) queues = c->wf_queues;
+	if (sets < c->wf_sets) sets = c->wf_sets;
 	wf_free(c);
-	HIP_TRY(hipMalloc((void**)&c->wf.s0, paths * sizeof(float4)));
-	HIP_TRY(hipMalloc((void**)&c->wf.s1, paths * sizeof(float4)));
-	HIP_TRY(hipMalloc((void**)&c->wf.s2, paths * sizeof(float4)));
-	HIP_TRY(hipMalloc((void**)&c->wf.s3, paths * sizeof(float4)));
-	for (int k = 0; k < 4; ++k) HIP_TRY(hipMalloc((void**)&c->wf_b[k], paths * sizeof(float4)));
+	const size_t recs = paths * (size_t)sets;
+	HIP_TRY(hipMalloc((void**)&c->wf.s0, recs * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.s1, recs * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.s2, recs * sizeof(float4)));
+	HIP_TRY(hipMalloc((void**)&c->wf.s3, recs * sizeof(float4)));
 	HIP_TRY(hipMalloc((void**)&c->wf.rad, rad * sizeof(Rad3)));
-	for (int k = 0; k < queues; ++k) HIP_TRY(hipMalloc((void**)&c->wf.queue[k], paths * sizeof(int)));
+	for (int k = 0; k < queues; ++k) HIP_TRY(hipMalloc((void**)&c->wf.queue[k], recs * sizeof(int)));
 	HIP_TRY(hipMalloc((void**)&c->wf.counters, WF_COUNTER_INTS * sizeof(int))); // counts + traversal cursors, queues and retry queues
 	if (queues > 0) HIP_TRY(hipMalloc((void**)&c->wf.retry, paths * sizeof(int)));
 	c->wf_paths = paths;
 	c->wf_rad = rad;
 	c->wf_queues = queues;
+	c->wf_sets = sets;
 	return PTX_OK;
 }
 
@@ -1121,18 +1127,22 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	int batch = ctx->wf_batch;
 	while (batch > 1 && npt * (size_t)batch > ((size_t)1 << 28)) batch >>= 1;
 	if (batch > num_samples) batch = num_samples;
-	// 148 B of state per path: if the device cannot hold the preferred batch (other tenants, huge frames),
-	// halve it rather than fail; the result does not depend on the batch size
+	const int cus = ctx->cus;
+	const int maxb = ctx->cam.max_bounces;
+	// state sets: one per bounce that has segments when the bounce loop runs inside the launch (pt_segloop.h), else two in turn
+	const bool seg_loop = ctx->seg_mode == 1;
+	const int nsets = seg_loop ? (maxb > 1 ? maxb : 1) : 2;
+	// 64 B of state per path and set, a queue entry per set, 12 B of parked radiance: if the device cannot hold the preferred
+	// batch (other tenants, huge frames, deep bounce limits), halve it rather than fail; the result does not depend on the batch size
 	for (;;) {
-		rc = wf_ensure(ctx, (npt * (size_t)batch + WF_ROUNDS * PT_BLOCK), npix * (size_t)batch, scene->num_big);
+		rc = wf_ensure(ctx, (npt * (size_t)batch + WF_ROUNDS * PT_BLOCK), npix * (size_t)batch, scene->num_big, nsets);
 		if (rc == PTX_OK || batch == 1) break;
 		wf_free(ctx);
 		(void)hipGetLastError();   // clear the sticky out-of-memory status
 		batch >>= 1;
 	}
 	if (rc != PTX_OK) return rc;
-	const int cus = ctx->cus;
-	const int maxb = ctx->cam.max_bounces;
+	const size_t stride = ctx->wf_paths;
 	for (int s0 = first_sample; s0 < first_sample + num_samples; s0 += batch) {
 		const int b = (first_sample + num_samples - s0) < batch ? (first_sample + num_samples - s0) : batch;
 		WfParams wp = ctx->wf;
@@ -1147,30 +1157,48 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		wp.n_total = (int)(npt * (size_t)b);
 		wp.k0 = k0; wp.k1 = k1;
 		wp.num_big = scene->num_big;
+		wp.max_bounces = maxb;
+		wp.set_stride = stride;
+		wp.queue_stride = stride;
 		HIP_TRY(hipMemsetAsync(wp.counters, 0, WF_COUNTER_INTS * sizeof(int), ctx->stream));
 		for (int bounce = 0; bounce <= maxb; ++bounce) {
 			wp.bounce = bounce;
 			wp.is_last = bounce == maxb ? 1 : 0;
-			// compacted state, two sets in turn: this bounce writes set (bounce & 1) and reads the other
-			float4* const set_a[4] = {ctx->wf.s0, ctx->wf.s1, ctx->wf.s2, ctx->wf.s3};
-			float4* const* out = (bounce & 1) ? ctx->wf_b : set_a;
-			float4* const* in = (bounce & 1) ? set_a : ctx->wf_b;
-			wp.s0 = out[0]; wp.s1 = out[1]; wp.s2 = out[2]; wp.s3 = out[3];
-			wp.i0 = in[0]; wp.i1 = in[1]; wp.i2 = in[2]; wp.i3 = in[3];
 			size_t blocks = ((size_t)wp.n_total + WF_ROUNDS * PT_BLOCK - 1) / (WF_ROUNDS * PT_BLOCK);
 			if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
+			const bool lds_tables = ctx->seg_lds_tables && scene->dev.num_materials <= WF_LDS_MATS && scene->dev.num_textures <= WF_LDS_TEXS;
+			// the set this bounce's new rays are written to (and its traversals update): set `bounce` of the bounce-loop kernel,
+			// else the two sets in turn
+			const size_t out_set = seg_loop ? (size_t)bounce : (size_t)(bounce & 1);
 			prof_mark(ctx, 1);
-			if (collect_stats)
-				hipLaunchKernelGGL((wf_segment_kernel<PT_F_STATS, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
-			else
-				// material / texture-descriptor tables in LDS when they fit (pt_wavefront.h)
-				if (ctx->seg_lds_tables && scene->dev.num_materials <= WF_LDS_MATS && scene->dev.num_textures <= WF_LDS_TEXS)
+			if (seg_loop) {
+				// the kernel addresses every set and queue segment itself: base pointers
+				wp.s0 = ctx->wf.s0; wp.s1 = ctx->wf.s1; wp.s2 = ctx->wf.s2; wp.s3 = ctx->wf.s3;
+				for (int k = 0; k < scene->num_big; ++k) wp.queue[k] = ctx->wf.queue[k];
+				const size_t dyn = (size_t)(maxb > 0 ? maxb : 1) * (size_t)(1 + scene->num_big) * WSL_LIST_INTS * sizeof(int);
+				if (collect_stats)
+					hipLaunchKernelGGL((wf_segment_loop_kernel<PT_F_STATS, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
+				else if (lds_tables)
+					hipLaunchKernelGGL((wf_segment_loop_kernel<0, 1>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
+				else
+					hipLaunchKernelGGL((wf_segment_loop_kernel<0, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
+			} else {
+				const size_t in_set = (size_t)((bounce & 1) ^ 1);
+				wp.s0 = ctx->wf.s0 + out_set * stride; wp.s1 = ctx->wf.s1 + out_set * stride; wp.s2 = ctx->wf.s2 + out_set * stride; wp.s3 = ctx->wf.s3 + out_set * stride;
+				wp.i0 = ctx->wf.s0 + in_set * stride; wp.i1 = ctx->wf.s1 + in_set * stride; wp.i2 = ctx->wf.s2 + in_set * stride; wp.i3 = ctx->wf.s3 + in_set * stride;
+				if (collect_stats)
+					hipLaunchKernelGGL((wf_segment_kernel<PT_F_STATS, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+				else if (lds_tables)   // material / texture-descriptor tables in LDS when they fit (pt_wavefront.h)
 					hipLaunchKernelGGL((wf_segment_kernel<0, 1>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
 				else
 					hipLaunchKernelGGL((wf_segment_kernel<0, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+			}
 			prof_mark(ctx, 1);
 			HIP_TRY(hipGetLastError());
 			if (wp.is_last) break;
+			// the traversal kernels see ONE set and ONE queue segment: this bounce's
+			wp.s0 = ctx->wf.s0 + out_set * stride; wp.s1 = ctx->wf.s1 + out_set * stride; wp.s2 = ctx->wf.s2 + out_set * stride; wp.s3 = ctx->wf.s3 + out_set * stride;
+			for (int k = 0; k < scene->num_big; ++k) wp.queue[k] = ctx->wf.queue[k] + (seg_loop ? out_set * stride : 0);
 			for (int k = 0; k < scene->num_big; ++k) {
 				prof_mark(ctx, 0);
 				launch_traversal(ctx, scene, wp, scene->big_object[k], k, collect_stats);
