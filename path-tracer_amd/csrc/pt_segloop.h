@@ -27,12 +27,26 @@
 //   2. one new ray per lane: cheap objects inline. Rays that enter a multi-node mesh are written to their state set
 //      and queues; the others go back into the pool with their hit.
 // Stage A and the pool share storage (a barrier separates each batch of reads from the writes that may reuse it).
+//
+// Measured (headline, 128-sample passes, ms per launch averaged over the six launches of a pass): per-bounce kernel 6.41;
+// this kernel 5.70 (launches of a pass: 21.6 / 3.2 / 4.3 / 2.5 / 1.8 / 0.8 ms against 8.6 / 12.5 / 10.2 / 4.0 / 2.5 / 0.9).
+// 96 registers and 30.7 KB of LDS: FIVE waves per SIMD, which is where the gain comes from as much as from the saved state
+// traffic - with the material / texture-descriptor tables in LDS as well (39.4 KB, four waves) it runs at 6.58 ms, so the
+// tables stay in global memory here. Two restructurings were built, pass every parity test, and were slower:
+//   * two LDS queues per WORKGROUP (hits to shade / rays to intersect, growing towards each other in the same 512 entries)
+//     with every step a full 256 lanes, shade or intersect: 6.2-6.4 ms (five and three barriers per 256-entry step
+//     instead of seven per ~800 entry-steps);
+//   * the same two queues per WAVE, 128 entries, no barrier anywhere, slots and queue entries reserved per wave in runs of
+//     256 (unused ones filled with a dead path id / a duplicate queue entry), persistent grid: 6.5-6.8 ms at four or five
+//     waves per SIMD, with or without a separate generate step in the launch of bounce 0.
 #pragma once
 #include "pt_wavefront.h"
 
 #define WSL_WORDS 15   // o (3), d (3), mask (3), path, meta, flags | tri, t, u, v
 // per (bounce, list) in dynamic LDS: count of this iteration, cursor of phase 2, reserved base
 #define WSL_LIST_INTS 3
+// dynamic LDS of a launch, bytes
+#define WSL_DYN_BYTES(maxb, nlists) ((size_t)((maxb) > 0 ? (maxb) : 1) * (size_t)(nlists) * WSL_LIST_INTS * sizeof(int))
 // input cursor of the segment launch of bounce b (5th region of the counter block)
 #define WF_SCUR(wp, b) ((wp).counters[4 * (PT_WF_MAX_BOUNCES + 1) * (1 + PT_MAX_BIG) + (b)])
 

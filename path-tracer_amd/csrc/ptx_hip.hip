@@ -59,7 +59,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
-	int wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode;
+	int wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -124,7 +124,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu;
 	bool force_megakernel;
 };
 
@@ -145,9 +145,10 @@ static Tuning tuning_defaults() {
 	t.grp_pad_ppm = clampi(env_int("PTX_GRP_PAD_PPM", PT_GRP_PAD_PPM_DEFAULT), 0, 1000000);
 	// wide traversal (pt_wide.h): A/B configuration of the kernel and the most stack entries a lane may hold
 	t.grp_mode = clampi(env_int("PTX_GRP_MODE", 1), 0, 1);   // how a leaf's triangles are cut into groups of eight; read at scene upload
-	t.seg_lds_tables = env_int("PTX_SEG_LDS_TABLES", 1) != 0;
+	t.seg_lds_tables = clampi(env_int("PTX_SEG_LDS_TABLES", 1), 0, 2);
 	// segment kernel: 1 = bounce loop inside the launch (pt_segloop.h), 0 = one bounce per launch (wf_segment_kernel)
 	t.seg_mode = clampi(env_int("PTX_SEG_MODE", 1), 0, 1);
+	t.seg_blocks_per_cu = clampi(env_int("PTX_SEG_BLOCKS", 16), 1, 64);
 	// margin of the wide traversal's distance culling, relative to the best t (and absolute), in parts per million (pt_wide.h)
 	t.wide_margin_ppm = clampi(env_int("PTX_WIDE_MARGIN_PPM", 10000), 0, 1000000);
 	t.wide_cfg = env_int("PTX_WIDE_CFG", 0);
@@ -167,6 +168,7 @@ static void tune_defaults(PtxCtx* c) {
 	c->wide_margin_ppm = t.wide_margin_ppm;
 	c->seg_lds_tables = t.seg_lds_tables;
 	c->seg_mode = t.seg_mode;
+	c->seg_blocks_per_cu = t.seg_blocks_per_cu;
 	c->wide_scap = t.wide_scap;
 }
 
@@ -179,8 +181,9 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d.force_megakernel : value != 0;
 	else if (!strcmp(key, "grp_pad_ppm")) ctx->grp_pad_ppm = value < 0 ? d.grp_pad_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "grp_mode")) ctx->grp_mode = value < 0 ? d.grp_mode : clampi(value, 0, 1);
-	else if (!strcmp(key, "seg_lds_tables")) ctx->seg_lds_tables = value < 0 ? d.seg_lds_tables : (value != 0);
+	else if (!strcmp(key, "seg_lds_tables")) ctx->seg_lds_tables = value < 0 ? d.seg_lds_tables : clampi(value, 0, 2);
 	else if (!strcmp(key, "seg_mode")) ctx->seg_mode = value < 0 ? d.seg_mode : clampi(value, 0, 1);
+	else if (!strcmp(key, "seg_blocks")) ctx->seg_blocks_per_cu = value < 0 ? d.seg_blocks_per_cu : clampi(value, 1, 64);
 	else if (!strcmp(key, "wide_margin_ppm")) ctx->wide_margin_ppm = value < 0 ? d.wide_margin_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "wide_cfg")) ctx->wide_cfg = value < 0 ? d.wide_cfg : value;
 	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
@@ -1130,7 +1133,8 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	const int cus = ctx->cus;
 	const int maxb = ctx->cam.max_bounces;
 	// state sets: one per bounce that has segments when the bounce loop runs inside the launch (pt_segloop.h), else two in turn
-	const bool seg_loop = ctx->seg_mode == 1;
+	// (its per-wave run table needs (bounces x lists) LDS entries: scenes with dozens of multi-node meshes AND deep bounce limits keep the per-bounce kernel)
+	const bool seg_loop = ctx->seg_mode == 1 && WSL_DYN_BYTES(maxb, 1 + scene->num_big) <= 16 * 1024;
 	const int nsets = seg_loop ? (maxb > 1 ? maxb : 1) : 2;
 	// 64 B of state per path and set, a queue entry per set, 12 B of parked radiance: if the device cannot hold the preferred
 	// batch (other tenants, huge frames, deep bounce limits), halve it rather than fail; the result does not depend on the batch size
@@ -1166,7 +1170,11 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 			wp.is_last = bounce == maxb ? 1 : 0;
 			size_t blocks = ((size_t)wp.n_total + WF_ROUNDS * PT_BLOCK - 1) / (WF_ROUNDS * PT_BLOCK);
 			if (blocks > (size_t)cus * 16) blocks = (size_t)cus * 16;
-			const bool lds_tables = ctx->seg_lds_tables && scene->dev.num_materials <= WF_LDS_MATS && scene->dev.num_textures <= WF_LDS_TEXS;
+			// the bounce-loop kernel's waves are persistent (every wave ends with a tail of partly filled steps): as many workgroups as the chip holds
+			if (seg_loop && blocks > (size_t)cus * (size_t)ctx->seg_blocks_per_cu) blocks = (size_t)cus * (size_t)ctx->seg_blocks_per_cu;
+			// material / texture-descriptor tables in LDS: the per-bounce kernel gains 2.5 % from them; the bounce-loop kernel loses its fifth
+			// wave per SIMD to them (39.4 KB per workgroup instead of 30.7: 6.58 vs 5.70 ms per launch), so there they need seg_lds_tables = 2
+			const bool lds_tables = (seg_loop ? ctx->seg_lds_tables >= 2 : ctx->seg_lds_tables >= 1) && scene->dev.num_materials <= WF_LDS_MATS && scene->dev.num_textures <= WF_LDS_TEXS;
 			// the set this bounce's new rays are written to (and its traversals update): set `bounce` of the bounce-loop kernel,
 			// else the two sets in turn
 			const size_t out_set = seg_loop ? (size_t)bounce : (size_t)(bounce & 1);
@@ -1175,7 +1183,7 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				// the kernel addresses every set and queue segment itself: base pointers
 				wp.s0 = ctx->wf.s0; wp.s1 = ctx->wf.s1; wp.s2 = ctx->wf.s2; wp.s3 = ctx->wf.s3;
 				for (int k = 0; k < scene->num_big; ++k) wp.queue[k] = ctx->wf.queue[k];
-				const size_t dyn = (size_t)(maxb > 0 ? maxb : 1) * (size_t)(1 + scene->num_big) * WSL_LIST_INTS * sizeof(int);
+				const size_t dyn = WSL_DYN_BYTES(maxb, 1 + scene->num_big);
 				if (collect_stats)
 					hipLaunchKernelGGL((wf_segment_loop_kernel<PT_F_STATS, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
 				else if (lds_tables)
