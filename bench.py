@@ -12,17 +12,26 @@ collective) and ONE all-reduce (RCCL) of the float accumulation buffers closes t
 
 The timed region ends when the accumulated buffer is resident on rank 0's HOST.
 
+    python bench.py --gpus N --total-spp S      STRONG scaling: a step is one image of S samples per pixel, split
+over the N ranks by sample index (rank g renders spp_split.sample_range(g, N, S)), all-reduced and brought to rank 0's
+host inside the step; "scaling": "strong". Without the flag the run is the weak-scaling contract above, and a MEASURED
+strong leg of 1000 spp (north_star's target: 125 per GPU at N = 8) is appended as config.time_to_1k_spp_s.
+
 Prints one JSON line (rank 0) with the contract fields plus
   "roofline"      for the dominant kernel class of this run: wf_traverse_wide_kernel (traversal + ray/triangle
                   tests of the rays queued for a multi-node mesh) or wf_segment_kernel (ray generation, shading,
                   cheap objects); since the wide traversal they take about the same time, the other one is reported
                   under "other_kernel". Neither HBM nor MFMA bounds them (the trees are cache-resident, nothing
                   is a dense contraction), so `bound` names the unit that does: the larger of the vector-memory front end (texture-addresser busy) and VALU
-                  issue, from the committed PMC passes (profiles/r02_pmc.json, recomputable from them
-                  and profiles/r02_kernel_stats.csv alone) rescaled to the launch time measured live
+                  issue, from the committed PMC passes (profiles/r03_pmc.json, recomputable from them
+                  and profiles/r03_kernel_stats.csv alone; stamped with the commit and a hash of the kernel
+                  sources: if that hash is not the tree's, or the live launch time is off by more than 10 %,
+                  the view says "pmc": "stale" and carries no bound / frac) rescaled to the launch time measured live
                   here with HIP event pairs on the library's stream. `executed` = bytes and flops the
                   kernel really requests / computes, counted live on the same samples by its counting
-                  twin; `logical` = the reference algorithm's figures of SURVEY.md 8(d), a side field.
+                  twin; `logical` = the reference algorithm's figures of SURVEY.md 8(d), a side field;
+                  `algorithmic` (in each kernel's view) = the HBM bytes the kernel cannot avoid (path state in /
+                  out, queue entries, shading records, texels, parked radiance) over its launch time against 8 TB/s.
   "cpu_baseline"  the CPU oracle (a straight multithreaded port, oracle/) timed on this box's host
                   cores on a bounded sample of the same workload (+ a 1-thread figure).
 """
@@ -44,8 +53,19 @@ VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: peak FP32 vector
 
 L2_PEAK_GBS = 34500.0       # MI355X_MICROARCH.md: L2 (per XCD, aggregate) ~34.5 TB/s
 PEAK_CLOCK_GHZ = 2.4        # MI355X_MICROARCH.md: max clock
-CUS, SIMDS = 256, 1024
-PMC_FILE = os.path.join("profiles", "r02_pmc.json")
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")
+
+
+def csrc_sha1():
+    """sha1 over the kernel sources and the build flags (the same function stamps the PMC file: tools/summarize_round.py)"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "path-tracer_amd")
+    for f in sorted(glob.glob(os.path.join(base, "csrc", "*"))) + [os.path.join(base, "Makefile")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def logical_bytes_and_flops(st):
@@ -67,16 +87,20 @@ def executed_bytes_and_flops(st):
 
 
 def load_pmc(kernel_prefix):
-    """Counter sums and derived fractions of the committed PMC passes (tools/profile_r02.sh) for one kernel."""
+    """(entry, file header) of the committed PMC passes (tools/profile_round.sh) for one kernel, matched on the kernel
+    name up to its first template arguments; (None, header) if the file has no such kernel."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as fh:
             d = json.load(fh)
     except (OSError, ValueError):
-        return None
+        return None, None
+    head = {k: d.get(k) for k in ("round", "commit", "csrc_sha1", "compute_units")}
     for name, e in d.get("kernels", {}).items():
         if name.replace(" ", "").startswith(kernel_prefix.replace(" ", "")):
-            return e
-    return None
+            e = dict(e)
+            e["full_name"] = name
+            return e, head
+    return None, head
 
 
 def main():
@@ -95,6 +119,10 @@ def main():
                     help="development only: every rank uses cuda:0 and the collective runs over gloo, to exercise the N>1 "
                          "code path on a one-GPU box (the reported number is then meaningless)")
     ap.add_argument("--cpu-spp", type=int, default=24)
+    ap.add_argument("--total-spp", type=int, default=0,
+                    help="strong scaling: a step is ONE image of this many samples per pixel split over the ranks (all-reduce and "
+                         "download to rank 0 inside the step)")
+    ap.add_argument("--no-strong-leg", action="store_true", help="weak mode: skip the measured 1000-spp strong leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,6 +168,10 @@ def main():
         raise SystemExit(f"bench.py: texture files missing beyond the known set {sorted(KNOWN_MISSING_TEXTURES)}: {tex_failed}")
     ctx = H.pth_context()
     scene = H.pth_scene_device()
+    cu_count = C.c_int(0)
+    pt.check(L.ptx_device_info(local_rank, None, 0, C.byref(cu_count), None, None))
+    CUS = cu_count.value or 256
+    SIMDS = 4 * CUS
     n_pix = cam.width * cam.height
     n_tris = desc.contents.num_triangles
 
@@ -156,7 +188,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sys.path.insert(0, os.path.join(ROOT, "path-tracer_amd"))
+    from spp_split import sample_range
+    strong = args.total_spp > 0
+    host_accum = np.empty((n_pix, 4), np.float32) if rank == 0 else None
+
+    def strong_image(i, total):
+        """One image of `total` samples per pixel: this rank's share of the sample range, ONE all-reduce, rank 0's host copy."""
+        first, count = sample_range(rank, world, total, i * total)
+        if count > 0:
+            pt.check(L.ptx_render_samples(ctx, scene, first, count, args.seed, 0), "ptx_render_samples")
+        pt.check(L.ptx_render_sync(ctx))
+        if world > 1:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        if rank == 0:
+            pt.check(L.ptx_accum_download(ctx, host_accum.ctypes.data_as(C.POINTER(C.c_float))), "ptx_accum_download")
+
     def step(i):
+        if strong:
+            accum.zero_()
+            torch.cuda.synchronize()
+            strong_image(i, args.total_spp)
+            return
         # global sample indices: step-major, rank-minor, disjoint across ranks and steps
         first = (i * world + rank) * spp
         pt.check(L.ptx_render_samples(ctx, scene, first, spp, args.seed, 0), "ptx_render_samples")
@@ -175,13 +229,13 @@ def main():
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
     pt.check(L.ptx_timer_end(ctx, C.byref(kernel_ms)))     # also waits for the launches
-    if world > 1:
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM)      # the one exchange step of the job
-        torch.cuda.synchronize()
-    if rank == 0:
-        # "... to accumulated buffer resident on rank 0 host" (33 MB over PCIe, once per image)
-        host_accum = np.empty((n_pix, 4), np.float32)
-        pt.check(L.ptx_accum_download(ctx, host_accum.ctypes.data_as(C.POINTER(C.c_float))), "ptx_accum_download")
+    if not strong:
+        if world > 1:
+            dist.all_reduce(accum, op=dist.ReduceOp.SUM)      # the one exchange step of the job
+            torch.cuda.synchronize()
+        if rank == 0:
+            # "... to accumulated buffer resident on rank 0 host" (33 MB over PCIe, once per image)
+            pt.check(L.ptx_accum_download(ctx, host_accum.ctypes.data_as(C.POINTER(C.c_float))), "ptx_accum_download")
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -201,6 +255,20 @@ def main():
     else:
         total_rays, max_elapsed, max_kernel_ms = float(stats.rays), elapsed, float(kernel_ms.value)
 
+    # ---- measured strong-scaling leg (weak mode): north_star's 1000 spp split over the ranks, timed to rank 0's host ----
+    strong_1k = None
+    if not strong and not args.no_strong_leg:
+        accum.zero_()
+        barrier()
+        ts = time.perf_counter()
+        strong_image(1 << 10, 1000)      # sample indices far from the timed steps'
+        barrier()
+        strong_1k = time.perf_counter() - ts
+        if world > 1:
+            tmx = torch.tensor([strong_1k], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+            strong_1k = tmx[0].item()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -213,7 +281,9 @@ def main():
         pt.check(L.ptx_ctx_tune(ctx, b"trav_variant", variant))
         pt.check(L.ptx_stats_reset(ctx))
         for i in range(args.warmup, args.warmup + args.steps):
-            pt.check(L.ptx_render_samples(ctx, scene, (i * world + rank) * spp, spp, args.seed, 1))
+            first, count = sample_range(rank, world, args.total_spp, i * args.total_spp) if strong else ((i * world + rank) * spp, spp)
+            if count > 0:
+                pt.check(L.ptx_render_samples(ctx, scene, first, count, args.seed, 1))
         pt.check(L.ptx_render_sync(ctx))
         st = pt.PtxStats()
         pt.check(L.ptx_stats_get(ctx, C.byref(st)))
@@ -226,27 +296,43 @@ def main():
     xb, xf = executed_bytes_and_flops(xd)
     lb, lf = logical_bytes_and_flops(cd)
 
-    def kernel_view(kernel, class_ms, class_n):
+    src_hash = csrc_sha1()
+
+    def kernel_view(kernel, class_ms, class_n, algo_bytes_per_step, algo_formula):
         """bound / achieved / peak / frac of one kernel class: the larger of texture-addresser busy and VALU issue at
-        2 cycles per wave64 instruction, from the committed PMC passes rescaled to the launch time measured live."""
+        2 cycles per wave64 instruction, from the committed PMC passes rescaled to the launch time measured live.
+        The PMC file is used only if it was made from THIS tree's kernel sources and its launch time is within 10 %
+        of the live one; else the view says "pmc": "stale" and carries no bound / frac."""
         n_launch = max(1, class_n)
         launch_ms = float(class_ms) / n_launch
         launch_s = max(launch_ms * 1e-3, 1e-12)
+        algo_launch = algo_bytes_per_step * args.steps / n_launch
         view = {"kernel": kernel, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                 "launch_ms": round(launch_ms, 4), "launches": class_n,
-                "share_of_step": round(float(class_ms) / max(1e-9, float(kernel_ms.value)), 4), "pmc": None}
-        pmc = load_pmc(kernel)
+                "share_of_step": round(float(class_ms) / max(1e-9, float(kernel_ms.value)), 4), "pmc": None,
+                # what the kernel cannot avoid moving to / from HBM, over its launch time, against the HBM rate
+                "algorithmic": {"bytes_per_launch": round(algo_launch), "achieved": round(algo_launch / launch_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                "unit": "GB/s", "frac": round(algo_launch / launch_s / 1e9 / HBM_PEAK_GBS, 4), "bytes": algo_formula}}
+        pmc, head = load_pmc(kernel)
         if not (pmc and pmc.get("derived", {}).get("ta_busy_frac") and pmc.get("avg_ns_kernel_trace")):
+            view["pmc"] = "absent" if head is None or pmc is None else "incomplete"
             return view
+        prof_ms = pmc["avg_ns_kernel_trace"] * 1e-6
+        if head.get("csrc_sha1") != src_hash or abs(prof_ms - launch_ms) > 0.10 * launch_ms:
+            view["pmc"] = "stale"
+            view["pmc_detail"] = (f"{PMC_FILE} (commit {head.get('commit')}): kernel sources {'differ from' if head.get('csrc_sha1') != src_hash else 'match'} "
+                                  f"this tree's; launch time there {prof_ms:.3f} ms, here {launch_ms:.3f} ms")
+            return view
+        view["kernel"] = pmc["full_name"]
         d, c, nd = pmc["derived"], pmc["counters"], pmc["dispatches"]
         # (the committed passes are of the headline workload: for another scene the fractions are only indicative)
-        scale = pmc["avg_ns_kernel_trace"] * 1e-6 / launch_ms if launch_ms > 0 else 1.0
+        scale = prof_ms / launch_ms if launch_ms > 0 else 1.0
         ta = d["ta_busy_frac"] * scale
         valu2 = d.get("valu_issue_frac_2cyc", 0.0) * scale
         clock = d.get("clock_ghz", PEAK_CLOCK_GHZ)
         view["traffic"] = round(d["hbm_side_bytes_per_launch"]) if "hbm_side_bytes_per_launch" in d else None
         if ta >= valu2:
-            view["bound"], view["unit"] = "vmem", "Gcycle/s busy, summed over the 256 texture addressers (one per CU)"
+            view["bound"], view["unit"] = "vmem", f"Gcycle/s busy, summed over the {CUS} texture addressers (one per CU)"
             achieved, peak = c["TA_TA_BUSY_sum"] / nd / launch_s / 1e9, CUS * clock
         else:
             view["bound"], view["unit"] = "valu-issue", "G wave64 VALU instructions/s (2 cycles each per SIMD)"
@@ -255,8 +341,8 @@ def main():
         l2_gbs = c.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0 / nd / launch_s / 1e9
         hbm_gbs = d.get("hbm_side_bytes_per_launch", 0.0) / launch_s / 1e9
         view["pmc"] = {
-            "source": PMC_FILE + " + profiles/r02_kernel_stats.csv (tools/profile_r02.sh; launch time there "
-                      f"{pmc['avg_ns_kernel_trace'] * 1e-6:.3f} ms, here {launch_ms:.3f} ms)",
+            "source": f"{PMC_FILE} + profiles/{head.get('round')}_kernel_stats.csv (tools/profile_round.sh, commit {head.get('commit')}, same kernel sources "
+                      f"as this tree; launch time there {prof_ms:.3f} ms, here {launch_ms:.3f} ms)",
             "clock_ghz": round(clock, 3),
             "ta_busy_frac": round(ta, 4),
             "valu_issue_frac_2cyc_per_inst": round(valu2, 4),
@@ -272,19 +358,38 @@ def main():
         }
         return view
 
+    # Algorithmic HBM bytes per step (SURVEY 8d's per-ray terms, restated for this pipeline's data layout; the trees, the
+    # cheap objects and the material tables are cache-resident and not counted):
+    #   segment kernel: a ray that needs a traversal is written as a 64-B state record and read back after the traversal
+    #   (128 B), plus a 4-B queue entry per mesh it enters; a shaded mesh hit reads its 64-B tri_shade record, a textured one a
+    #   16-B texel; a finished path parks 12 B of radiance. Rays that never enter a multi-node mesh stay in LDS (pt_segloop.h).
+    #   traversal kernel: 4-B queue entry + origin, direction, current best (36 B read) + the closest-hit words (28 B) per ray.
+    maxb = cam.max_ray_bounces
+    live = (C.c_int32 * (maxb + 1))()
+    queued = (C.c_int32 * (maxb + 1))()
+    pt.check(L.ptx_wavefront_counts(ctx, maxb, live, queued))      # the LAST pass (<= 128 samples of every pixel)
+    last_first, last_count = sample_range(rank, world, args.total_spp, 0) if strong else (0, spp)
+    wf_batch = int(os.environ.get("PTX_WF_BATCH", "128"))
+    last_pass_spp = (last_count % wf_batch) or min(wf_batch, last_count) or 1
+    per_step = (last_count / last_pass_spp)
+    state_records = sum(live) * per_step
+    queue_entries = sum(queued) * per_step
+    k_steps = float(args.steps)
+    seg_bytes = 128.0 * state_records + 4.0 * queue_entries + (64.0 * cd["hit_mesh"] + 16.0 * cd["hit_textured"] + 12.0 * cd["paths"]) / k_steps
+    trav_bytes = 68.0 * cd["trav_rays"] / k_steps
+    seg_formula = "128 B x state records written and read back + 4 B x queue entries + 64 B x mesh hits shaded + 16 B x textured hits + 12 B x paths"
+    trav_formula = "68 B x traversals (queue entry, ray and current best in, closest hit out); tree and triangles are cache-resident"
+
     # The two kernel classes of a step (HIP event pairs around every launch; a traversal pair spans the wide kernel
     # and the exact kernel's retry launch behind it). Since the wide traversal they take about the same time on the
     # headline scene, so the dominant one is whichever is larger in THIS run and the other is reported beside it.
-    trav = kernel_view("wf_traverse_wide_kernel<0,", trav_ms.value, trav_n.value) if trav_n.value > 0 else None
-    seg = kernel_view("wf_segment_kernel<0,", seg_ms.value, seg_n.value)
+    seg_name = "wf_segment_loop_kernel<0," if os.environ.get("PTX_SEG_MODE", "1") != "0" else "wf_segment_kernel<0,"
+    trav = kernel_view("wf_traverse_wide_kernel<0,", trav_ms.value, trav_n.value, trav_bytes, trav_formula) if trav_n.value > 0 else None
+    seg = kernel_view(seg_name, seg_ms.value, seg_n.value, seg_bytes, seg_formula)
     trav_dominant = trav is not None and trav_ms.value >= seg_ms.value
     dom, other = (trav, seg) if trav_dominant else (seg, trav)
     trav_s = max(float(trav_ms.value) * 1e-3, 1e-12)
-    if dom["frac"] is None:
-        # no committed PMC passes for this kernel: fall back to the executed flops against the FP32 vector peak
-        x_tflops = xf / trav_s / 1e12 if trav is not None else 0.0
-        dom.update({"bound": "valu", "achieved": round(x_tflops, 3), "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(x_tflops / VALU_PEAK_TFLOPS, 4)})
+    # (a view whose PMC passes are absent or stale keeps bound / frac = null: its "algorithmic" and "executed" figures are live)
     xtr = max(1, xd["trav_rays"])
     roofline = dict(dom)
     roofline.update({
@@ -313,8 +418,9 @@ def main():
         "note": "bound = the unit with the highest utilisation in the committed PMC passes, rescaled to this run's launch time: "
                 "the vector-memory front end (texture-addresser busy) against VALU issue at 2 cycles per wave64 instruction "
                 "(MI355X_MICROARCH.md). Not HBM: the trees are cache-resident and the path state streams at a third of the HBM "
-                "rate (pmc.hbm_side; traffic = measured L2-miss side per launch). Sensitivity of the wide traversal: 24 extra VALU "
-                "instructions per node visit cost 1 %, one extra L1-hitting load per visit 3 % (DESIGN.md 3.4)",
+                "rate (pmc.hbm_side; traffic = measured L2-miss side per launch; `algorithmic` = unavoidable HBM bytes over the launch time "
+                "against 8 TB/s). Sensitivity of the wide traversal: 24 extra VALU instructions per node visit cost 1 %, one extra "
+                "L1-hitting load per visit 3 % (DESIGN.md 3.4)",
     })
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------
@@ -351,13 +457,22 @@ def main():
     out = {
         "metric": "Mrays/s (whole node), Lamborghini 1920x1080", "value": round(total_rays / max_elapsed / 1e6, 2),
         "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(max_elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(max_elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"scenes/scene_{args.scene}.json at {cam.width}x{cam.height}, textures "
                                f"{'on' if args.textures else 'off'} ({desc.contents.num_textures} texture files loaded, {n_tex_failed} absent"
                                f"{': ' + ', '.join(tex_failed) if tex_failed else ''}), 5 bounces; lp560.obj absent -> procedural stand-in car",
-                   "triangles": n_tris, "spp_per_step_per_gpu": spp, "samples_per_s": round(n_pix * spp * args.steps * world / max_elapsed, 1),
-                   "time_to_1k_spp_s": round(1000.0 / (spp * args.steps * world / max_elapsed), 2),
+                   "triangles": n_tris,
+                   **({"total_spp_per_step": args.total_spp, "spp_per_step_per_gpu": round(args.total_spp / world, 2),
+                       "samples_per_s": round(n_pix * args.total_spp * args.steps / max_elapsed, 1),
+                       "time_to_total_spp_s": round(max_elapsed / args.steps, 4),
+                       "time_to_1k_spp_s": round(max_elapsed / args.steps * 1000.0 / args.total_spp, 4),
+                       "time_to_1k_spp_is": "scaled from the measured image of total_spp_per_step samples (all-reduce and download to rank 0 included)"}
+                      if strong else
+                      {"spp_per_step_per_gpu": spp, "samples_per_s": round(n_pix * spp * args.steps * world / max_elapsed, 1),
+                       "time_to_1k_spp_s": round(strong_1k, 4) if strong_1k is not None else round(1000.0 / (spp * args.steps * world / max_elapsed), 2),
+                       "time_to_1k_spp_is": ("MEASURED: one image of 1000 spp split over the ranks by sample index, one all-reduce, on rank 0's host"
+                                             if strong_1k is not None else "extrapolated from the weak-scaling steps")}),
                    "parallelism": f"spp-split x{world}"},
         "roofline": roofline, "cpu_baseline": cpu,
     }

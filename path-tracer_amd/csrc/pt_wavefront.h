@@ -544,106 +544,6 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 #undef WFS_CLOCK
 }
 
-// KD traversal of the rays queued for one multi-node mesh; merges into the path's closest-hit record.
-//
-// Persistent waves with lane refill: every wave owns one contiguous chunk of the queue and a
-// wave-private cursor (no atomics). A lane whose ray has finished takes the next ray of the chunk at
-// the top of the next traversal step, so a long ray no longer holds 63 finished lanes hostage
-// (measured before: 29 % useful lanes in this kernel). Chunks are large (queue / resident waves,
-// ~1000+ rays), which evens out the total work per wave.
-template <int FLAGS, int PREFETCH, int OCC, int CHUNK>
-__global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
-	extern __shared__ int lds_stack[];
-	const int tid = threadIdx.x, lane = tid & 63;
-	int* stack = lds_stack + tid;
-	const DevObject& ob = sc.objects[obj_index];
-	const int n = WF_CNT(wp, wp.bounce, 1 + slot_index);
-	const int* __restrict__ queue = wp.queue[slot_index];
-	TraceCounters cnt = {0, 0, 0, 0, 0, 0};
-	uint64_t act = 0, tot = 0, n_taken = 0, dg0 = 0, dg1 = 0, dg2 = 0, dg3 = 0;
-
-	WaveFeed feed;
-	feed.exhausted = CHUNK == 0;
-	if (CHUNK == 0) {
-		// static split: wave w owns queue[n*w/W, n*(w+1)/W)
-		const long long nw = (long long)gridDim.x * (PT_BLOCK / 64);
-		const long long gw = (long long)blockIdx.x * (PT_BLOCK / 64) + (tid >> 6);
-		feed.next = (int)(((long long)n * gw) / nw);
-		feed.hi = (int)(((long long)n * (gw + 1)) / nw);
-	} else {
-		feed.next = feed.hi = 0;
-	}
-	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
-
-	bool active = false;
-	int path = 0;
-	float cur_d = 0.0f;
-	Ray ray;
-	TravState ts;
-	ts.curr = -1; ts.sp = 0; ts.tri = -1; ts.tmin = 0.0f; ts.bu = ts.bv = 0.0f; ts.intersects = false;
-
-	for (;;) {
-		// ---- refill idle lanes from the wave's chunk ----
-		for (int attempt = 0; attempt < 2; ++attempt) {
-			const unsigned long long idle = __ballot(!active);
-			if (idle == 0ull) break;
-			if (feed.next >= feed.hi) {
-				if (feed.exhausted) break;
-				feed_claim(feed, cursor, n, CHUNK);
-				if (feed.exhausted) break;
-			}
-			const int mine = feed.next + (int)__popcll(idle & ((1ull << lane) - 1ull));
-			if (!active && mine < feed.hi) {
-				if (FLAGS & PT_F_STATS) n_taken++;
-				path = queue[mine];
-				const float4 a0 = wp.s0[path], a1 = wp.s1[path];
-				init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
-				cur_d = a0.w;
-				trav_begin(ts, ob);
-				active = true;
-			}
-			feed.next += (int)__popcll(idle);
-		}
-		if (__ballot(active) == 0ull) break;
-		if (FLAGS & PT_F_STATS) { dg0 += active ? 1 : 0; if (lane == 0) dg1 += 64; }
-
-		uint32_t steps = 0;
-		if (active) {
-			float dbg = 1.0f;
-			const bool finished = traverse_step<FLAGS, PREFETCH>(sc, ob, obj_index, ray, stack, PT_BLOCK, ts, cnt, dbg, steps);
-			if (finished) {
-				if (ts.intersects && ts.tri >= 0) {
-					const f3 p = ray.o + ts.tmin * ray.d;
-					const float d = length3(p - ray.o);
-					const int cur_obj = __float_as_int(wp.s2[path].w);
-					// strict '<' in object order == smaller distance, ties to the lower object index
-					if (d < cur_d || (d == cur_d && cur_obj >= 0 && obj_index < cur_obj)) {
-						wp.s0[path].w = d;
-						wp.s1[path].w = ts.tmin;
-						wp.s2[path].w = __int_as_float(obj_index);
-						store_hit(wp.s3 + path, ts.tri, ts.bu, ts.bv);
-					}
-				}
-				active = false;
-			}
-		}
-		if (FLAGS & PT_F_STATS) {
-			// lane utilisation of the traversal: own steps vs 64 x the slowest lane of this step
-			uint32_t mx = steps;
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) {
-				const uint32_t v = (uint32_t)__shfl_xor((int)mx, o, 64);
-				mx = v > mx ? v : mx;
-			}
-			act += steps;
-			if (lane == 0) tot += 64ull * mx;
-		}
-	}
-	stats_flush(wp.stats, cnt, 0, 0, 0, 0, 0, act, tot, (FLAGS & PT_F_STATS) != 0, n_taken, true);
-	if (FLAGS & PT_F_STATS) diag_flush(wp.stats, dg0, dg1, dg2, dg3);
-}
-
-// LDS staging area of leaf mode 4: per wave 64 slots of WF_STAGE_F4 float4, behind the traversal stacks
 #define WF_STAGE_F4 4
 #define WF_STAGE_BYTES ((PT_BLOCK / 64) * 64 * WF_STAGE_F4 * 16)
 
@@ -705,12 +605,12 @@ PT_DEV uint32_t row_min_u32(uint32_t x) {
 //   the leaves are worked off -> owners pop their stacks.
 template <int FLAGS, int OCC, int CHUNK, int ATHRESH, int FLAT>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index) {
+	static_assert(FLAT == 3 || FLAT == 4 || FLAT == 9, "leaf modes of the product build: 9 (default), 4 and 3 (fall-backs for deep trees); 0-2, 5-8 were A/B steps of rounds 1-2");
 	extern __shared__ int lds_stack[];
-	const int tid = threadIdx.x, lane = tid & 63, sub = lane & 31;
+	const int tid = threadIdx.x, lane = tid & 63;
 	// counting variant only: constant-rate clock read by lane 0, summed per phase into PtxStats.diag0..3
 	// (refill + commit, descent, leaf phase, of which unit steps of mode 5); tools/phase_clock.py
 #define WF_CLOCK() (((FLAGS & PT_F_STATS) && lane == 0) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
-	const bool upper = lane >= 32;
 	int* stack = lds_stack + tid;
 	const DevObject& ob = sc.objects[obj_index];
 	// the rays of this launch: the mesh's queue, or the retry queue the wide traversal left for it (pt_wide.h)
@@ -1062,7 +962,11 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 								if (k != 0xffffffffu && (win0 | win1)) {
 									const unsigned long long key = ((unsigned long long)k << 32) | (unsigned long long)cand;
 									atomicMin(&keys[owner], key);
-									if (keys[owner] == key) uvs[owner] = win0 ? make_float2(u.x, v.x) : make_float2(u.y, v.y);
+									// re-read through an atomic load (the word was just the target of other lanes' atomics: a plain load
+									// could legally be folded with the operand above); the wave executes both in lock-step
+									__builtin_amdgcn_wave_barrier();
+									if (__hip_atomic_load(&keys[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == key)
+										uvs[owner] = win0 ? make_float2(u.x, v.x) : make_float2(u.y, v.y);
 								}
 							} else
 							if ((lane & 3) == 0 && k != 0xffffffffu)
@@ -1237,126 +1141,6 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_coop_kernel(DevScen
 							hm &= ~clr;
 						}
 					}
-				}
-			}
-		} else
-		if (FLAT == 2) {
-			// Two steps (four owners) in flight: the broadcasts and triangle loads of step B are issued
-			// before step A is computed, so a wave has two independent memory round trips outstanding
-			// instead of one load -> wait -> compute chain per step.
-			struct Step {
-				int l0, l1;
-				float ox, oy, oz, dx, dy, dz;
-				float4 a, e1, e2;
-				bool valid;
-			};
-			auto pick = [&](Step& st) {
-				st.l0 = (int)__ffsll((long long)m) - 1;
-				m &= m - 1ull;
-				st.l1 = -1;
-				if (m != 0ull) { st.l1 = (int)__ffsll((long long)m) - 1; m &= m - 1ull; }
-			};
-			auto issue = [&](Step& st, int base) {
-				const bool on = !upper || st.l1 >= 0;
-				const int src = (upper && st.l1 >= 0) ? st.l1 : st.l0;
-				st.ox = __shfl(ray.o.x, src, 64); st.oy = __shfl(ray.o.y, src, 64); st.oz = __shfl(ray.o.z, src, 64);
-				st.dx = __shfl(ray.d.x, src, 64); st.dy = __shfl(ray.d.y, src, 64); st.dz = __shfl(ray.d.z, src, 64);
-				const int first = __shfl(leaf_first, src, 64);
-				const int count = __shfl(leaf_count, src, 64);
-				const int i = base + sub;
-				st.valid = on && i < count;
-				int idx = first + (i < count ? i : 0);          // always a loadable address: no branch before the loads
-				idx = idx < sc.num_tris ? idx : sc.num_tris - 1;
-				st.a = pa[idx]; st.e1 = pe1[idx]; st.e2 = pe2[idx];
-			};
-			auto finish = [&](const Step& st, int base) {
-				Ray br;
-				br.o = mk3(st.ox, st.oy, st.oz);
-				br.d = mk3(st.dx, st.dy, st.dz);
-				float t, u, v;
-				bool hit = tri_test_flat(br, mk3(st.a.x, st.a.y, st.a.z), mk3(st.e1.x, st.e1.y, st.e1.z), mk3(st.e2.x, st.e2.y, st.e2.z), t, u, v);
-				hit = hit && st.valid;
-				if (FLAGS & PT_F_STATS) { if (st.valid) { act++;  } if (lane == 0) { tot += 64;  } }
-				const unsigned long long hm = __ballot(hit);
-				uint32_t h0 = (uint32_t)hm, h1 = (uint32_t)(hm >> 32);
-				while ((h0 | h1) != 0u) {
-					const int w0 = h0 ? (int)__ffs((int)h0) - 1 : 0;
-					const int w1 = h1 ? 32 + (int)__ffs((int)h1) - 1 : 32;
-					const bool second = lane == st.l1;
-					const int w = second ? w1 : w0;
-					const float tt = __shfl(t, w, 64), uu = __shfl(u, w, 64), vv = __shfl(v, w, 64);
-					const bool mine = (lane == st.l0 && h0 != 0u) || (second && h1 != 0u);
-					if (mine) {
-						ts.intersects = true;
-						if (tt < ts.tmin) { ts.tmin = tt; ts.tri = leaf_first + base + (w & 31); ts.bu = uu; ts.bv = vv; }
-					}
-					h0 &= h0 - 1u;
-					h1 &= h1 - 1u;
-				}
-			};
-			auto extra_passes = [&](Step& st) {   // leaves with more than 32 triangles (rare)
-				const int c0 = __builtin_amdgcn_readlane(leaf_count, st.l0);
-				const int c1 = st.l1 >= 0 ? __builtin_amdgcn_readlane(leaf_count, st.l1) : 0;
-				const int cmax = c0 > c1 ? c0 : c1;
-				for (int base = 32; base < cmax; base += 32) { issue(st, base); finish(st, base); }
-			};
-			while (m != 0ull) {
-				Step A, B;
-				pick(A);
-				const bool has_b = m != 0ull;
-				issue(A, 0);
-				if (has_b) { pick(B); issue(B, 0); }
-				finish(A, 0);
-				if (has_b) finish(B, 0);
-				extra_passes(A);
-				if (has_b) extra_passes(B);
-			}
-		} else
-		while (m != 0ull) {
-			const int l0 = (int)__ffsll((long long)m) - 1;
-			m &= m - 1ull;
-			int l1 = -1;
-			if (m != 0ull) { l1 = (int)__ffsll((long long)m) - 1; m &= m - 1ull; }
-			const bool on = !upper || l1 >= 0;
-			const int src = (upper && l1 >= 0) ? l1 : l0;
-			const float ox = __shfl(ray.o.x, src, 64), oy = __shfl(ray.o.y, src, 64), oz = __shfl(ray.o.z, src, 64);
-			const float dx = __shfl(ray.d.x, src, 64), dy = __shfl(ray.d.y, src, 64), dz = __shfl(ray.d.z, src, 64);
-			const int first = __shfl(leaf_first, src, 64);
-			const int count_src = __shfl(leaf_count, src, 64); // every lane takes part: the source may sit in the other half
-			const int count = on ? count_src : 0;
-			const int c0 = __builtin_amdgcn_readlane(leaf_count, l0);
-			const int c1 = l1 >= 0 ? __builtin_amdgcn_readlane(leaf_count, l1) : 0;
-			const int cmax = c0 > c1 ? c0 : c1;
-			Ray br;
-			br.o = mk3(ox, oy, oz);
-			br.d = mk3(dx, dy, dz);
-			for (int base = 0; base < cmax; base += 32) {
-				const int i = base + sub;
-				bool hit = false;
-				float t = 0.0f, u = 0.0f, v = 0.0f;
-				if (i < count) {
-					const float4 a = pa[first + i], e1 = pe1[first + i], e2 = pe2[first + i];
-					if (FLAT) hit = tri_test_flat(br, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t, u, v);
-					else hit = tri_test(br, mk3(a.x, a.y, a.z), mk3(e1.x, e1.y, e1.z), mk3(e2.x, e2.y, e2.z), t, u, v);
-					if (FLAGS & PT_F_STATS) { act++;  }
-				}
-				if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64;  } }
-				const unsigned long long hm = __ballot(hit);
-				uint32_t h0 = (uint32_t)hm, h1 = (uint32_t)(hm >> 32);
-				// fold the hits into the owners in triangle order (the serial loop's order)
-				while ((h0 | h1) != 0u) {
-					const int w0 = h0 ? (int)__ffs((int)h0) - 1 : 0;
-					const int w1 = h1 ? 32 + (int)__ffs((int)h1) - 1 : 32;
-					const bool second = lane == l1;
-					const int w = second ? w1 : w0;
-					const float tt = __shfl(t, w, 64), uu = __shfl(u, w, 64), vv = __shfl(v, w, 64);
-					const bool mine = (lane == l0 && h0 != 0u) || (second && h1 != 0u);
-					if (mine) {
-						ts.intersects = true;
-						if (tt < ts.tmin) { ts.tmin = tt; ts.tri = leaf_first + base + (w & 31); ts.bu = uu; ts.bv = vv; }
-					}
-					h0 &= h0 - 1u;
-					h1 &= h1 - 1u;
 				}
 			}
 		}

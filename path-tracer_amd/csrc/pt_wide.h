@@ -50,7 +50,7 @@
 #define WFW_STACK_ENTRY_BYTES 6                                         /* link (4) + entry distance as bf16 (2) */
 #define WFW_SCAP_MAX 10   /* 10 x 6 B x 256 lanes + the waves' areas = 25.6 KB per workgroup: six workgroups per CU */
 
-template <int FLAGS, int OCC, int CHUNK, int TURN_MIN, int DRAIN_MIN, int KNOB = 0>
+template <int FLAGS, int OCC, int CHUNK, int TURN_MIN, int DRAIN_MIN>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index, int scap, float cull_rel, float cull_abs) {
 	static_assert(CHUNK >= 1 && CHUNK <= 128, "a chunk's queue entries are held two per lane");
 	static_assert(DRAIN_MIN >= 16 && DRAIN_MIN <= 64 && 63 + 256 < WFW_UNIT_CAP, "the unit list must hold one more iteration's appends");
@@ -82,16 +82,13 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 	feed.next = feed.hi = 0;
 	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
 
-	enum { IDLE = 0, DESCEND = 1, DONE = 2, TAKE = 3 };   // TAKE: the loads of a new ray are in flight
+	enum { IDLE = 0, DESCEND = 1, DONE = 2 };
 	int state = IDLE;
 	int path = 0, curr = 0, sp = 0, cur_obj_r = -1;
 	bool redo = false;
 	float cur_d = 0.0f, tmin = 0.0f;   // tmin: the CULLING bound = best t so far x cull_rel + cull_abs (see the header comment)
 	f3 o = mk3(0.0f), d = mk3(1.0f), inv = mk3(1.0f);
 	int nunits = 0;   // wave-uniform
-	int qa = 0, qb = 0, feed_base = 0;   // queue entries feed_base + lane and feed_base + 64 + lane of the wave's chunk
-	float4 ta0 = make_float4(0, 0, 0, 0), ta1 = ta0;
-	float tw = 0.0f;
 
 	// the wave tests listed units, sixteen per step, newest first; all of them, or while full steps remain
 	auto unit_steps = [&](bool all) {
@@ -196,10 +193,9 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 				const int slot = wave_append(&WF_RCNT(wp, wp.bounce, 1 + slot_index), again);
 				if (again) { wp.retry[slot] = path; if (FLAGS & PT_F_STATS) { x_retry++; if (redo) dg_over++; } }
 			}
-			// Refill. (A/B configuration KNOB 4 splits it in two halves: the queue entries of the wave's chunk are fetched when
-			// the chunk is claimed, a lane picks its entry out of a neighbour's register and only ISSUES the loads of its ray,
-			// which are taken up after the node visit below. Measured: no gain at 5 waves/SIMD, and its 11 extra registers cost
-			// the sixth wave, which is worth 4 %.)
+			// Refill: idle lanes take the next entries of the wave's chunk. (Splitting it - queue entries fetched when the chunk is
+			// claimed, the ray's loads issued here and taken up after the node visit - gained nothing at 5 waves/SIMD and its 11
+			// registers cost the sixth wave, which is worth 4 %.)
 			for (int attempt = 0; attempt < 2; ++attempt) {
 				const unsigned long long idle = __ballot(state == IDLE);
 				if (idle == 0ull) break;
@@ -207,43 +203,28 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 					if (feed.exhausted) break;
 					feed_claim(feed, cursor, n, CHUNK);
 					if (feed.exhausted) break;
-					feed_base = feed.next;
-					if (KNOB == 4) {
-						qa = feed_base + lane < feed.hi ? queue[feed_base + lane] : 0;
-						qb = feed_base + 64 + lane < feed.hi ? queue[feed_base + 64 + lane] : 0;
-					}
 				}
 				const int mine = feed.next + (int)__popcll(idle & lt);
-				const int qi = mine - feed_base;
-				const int ea = KNOB != 4 ? 0 : __shfl(qa, qi & 63, 64), eb = KNOB != 4 ? 0 : __shfl(qb, qi & 63, 64);
 				if (state == IDLE && mine < feed.hi) {
 					if (FLAGS & PT_F_STATS) n_taken++;
-					if (KNOB != 4) {   // the whole refill here; KNOB 4 (A/B) splits it: see below
-						path = queue[mine];
-						const float4 a0 = wp.s0[path], a1 = wp.s1[path];
-						cur_obj_r = __float_as_int(wp.s2[path].w);
-						o = mk3(a0.x, a0.y, a0.z);
-						d = mk3(a1.x, a1.y, a1.z);
-						inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-						cur_d = a0.w;
-						tmin = __builtin_huge_valf();
-						curr = root;
-						sp = 0;
-						redo = false;
-						keys[lane] = ~0ull;
-						flags[lane] = 0u;
-						state = DESCEND;
-					} else {
-						path = qi < 64 ? ea : eb;
-						ta0 = wp.s0[path];
-						ta1 = wp.s1[path];
-						tw = wp.s2[path].w;
-						state = TAKE;
-					}
+					path = queue[mine];
+					const float4 a0 = wp.s0[path], a1 = wp.s1[path];
+					cur_obj_r = __float_as_int(wp.s2[path].w);
+					o = mk3(a0.x, a0.y, a0.z);
+					d = mk3(a1.x, a1.y, a1.z);
+					inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+					cur_d = a0.w;
+					tmin = __builtin_huge_valf();
+					curr = root;
+					sp = 0;
+					redo = false;
+					keys[lane] = ~0ull;
+					flags[lane] = 0u;
+					state = DESCEND;
 				}
 				feed.next += (int)__popcll(idle);
 			}
-			if (__ballot(state == DESCEND || state == TAKE) == 0ull) break;   // queue drained, nothing in flight
+			if (__ballot(state == DESCEND) == 0ull) break;   // queue drained, nothing in flight
 		}
 
 		const unsigned long long ct1 = WFW_CLOCK();
@@ -256,18 +237,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		if (state == DESCEND) {
 			const float4* rec = wn + 4 * (size_t)curr;
 			const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3];
-			float ax = (f0.x - o.x) * inv.x, ay = (f0.y - o.y) * inv.y, az = (f0.z - o.z) * inv.z;
-			if (KNOB == 1) {   // sensitivity probe (A/B builds only): 24 dependent VALU instructions that change nothing
-				asm volatile("v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
-				             "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
-				             "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n"
-				             "v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0" : "+v"(ax));
-			}
-			if (KNOB == 2) {   // sensitivity probe: one more 4-B load from the record (an L1 hit), waited for inside the statement
-				float again;
-				asm volatile("global_load_dword %0, %1, off offset:16\n s_waitcnt vmcnt(0)" : "=v"(again) : "v"(rec) : "memory");
-				asm volatile("" :: "v"(again));
-			}
+			const float ax = (f0.x - o.x) * inv.x, ay = (f0.y - o.y) * inv.y, az = (f0.z - o.z) * inv.z;
 			const float sx = f0.w * inv.x, sy = f1.x * inv.y, sz = f1.y * inv.z;
 			const uint32_t w0 = __float_as_uint(f1.z), w1 = __float_as_uint(f1.w), w2 = __float_as_uint(f2.x),
 			               w3 = __float_as_uint(f2.y), w4 = __float_as_uint(f2.z), w5 = __float_as_uint(f2.w);
@@ -342,21 +312,6 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		WFW_APPEND(1u, gref0) WFW_APPEND(2u, gref1) WFW_APPEND(4u, gref2) WFW_APPEND(8u, gref3)
 #undef WFW_APPEND
 		if (nunits >= DRAIN_MIN) unit_steps(false);
-		// second half of the refill: the new rays start
-		if (state == TAKE) {
-			cur_obj_r = __float_as_int(tw);
-			o = mk3(ta0.x, ta0.y, ta0.z);
-			d = mk3(ta1.x, ta1.y, ta1.z);
-			inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-			cur_d = ta0.w;
-			tmin = __builtin_huge_valf();
-			curr = root;
-			sp = 0;
-			redo = false;
-			keys[lane] = ~0ull;
-			flags[lane] = 0u;
-			state = DESCEND;
-		}
 		dg_visit += (WFW_CLOCK() - ct1) - (dg_unit - du1);
 	}
 	// lane_steps_active of this kernel = rays sent to the exact kernel because their winning hit was not robust

@@ -2,7 +2,6 @@
 // Host side of the library: argument validation, the packed scene upload, launches.
 // There is no CPU fallback anywhere in this file: without a HIP device every compute
 // entry point returns an error.
-#include "pt_unified.h"
 #include "pt_wide.h"
 #include "pt_segloop.h"
 #include <cstdlib>
@@ -59,7 +58,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
-	int wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu;
+	int wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -124,7 +123,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_cfg, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu;
 	bool force_megakernel;
 };
 
@@ -140,6 +139,7 @@ static Tuning tuning_defaults() {
 	t.wf_batch = clampi(env_int("PTX_WF_BATCH", 128), 1, 256);
 	t.force_megakernel = env_int("PTX_MEGAKERNEL", 0) != 0;
 	t.trav_variant = env_int("PTX_TRAV_VARIANT", 0);
+	if (t.trav_variant != 7 && t.trav_variant != 9 && t.trav_variant != 14 && t.trav_variant != 15) t.trav_variant = 0;
 	t.trav_blocks_per_cu = clampi(env_int("PTX_TRAV_BLOCKS", 16), 1, 64);
 	// padding of the group boxes (pt_scene.h) relative to the mesh diagonal, in parts per million; read at scene upload
 	t.grp_pad_ppm = clampi(env_int("PTX_GRP_PAD_PPM", PT_GRP_PAD_PPM_DEFAULT), 0, 1000000);
@@ -151,7 +151,6 @@ static Tuning tuning_defaults() {
 	t.seg_blocks_per_cu = clampi(env_int("PTX_SEG_BLOCKS", 16), 1, 64);
 	// margin of the wide traversal's distance culling, relative to the best t (and absolute), in parts per million (pt_wide.h)
 	t.wide_margin_ppm = clampi(env_int("PTX_WIDE_MARGIN_PPM", 10000), 0, 1000000);
-	t.wide_cfg = env_int("PTX_WIDE_CFG", 0);
 	t.wide_scap = clampi(env_int("PTX_WIDE_SCAP", WFW_SCAP_MAX), 1, 32);
 	return t;
 }
@@ -163,7 +162,6 @@ static void tune_defaults(PtxCtx* c) {
 	c->trav_variant = t.trav_variant;
 	c->trav_blocks_per_cu = t.trav_blocks_per_cu;
 	c->grp_pad_ppm = t.grp_pad_ppm;
-	c->wide_cfg = t.wide_cfg;
 	c->grp_mode = t.grp_mode;
 	c->wide_margin_ppm = t.wide_margin_ppm;
 	c->seg_lds_tables = t.seg_lds_tables;
@@ -175,7 +173,11 @@ static void tune_defaults(PtxCtx* c) {
 extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	if (!ctx || !key) return fail(PTX_E_INVALID, "ptx_ctx_tune: NULL argument");
 	const Tuning d = tuning_defaults();
-	if (!strcmp(key, "trav_variant")) ctx->trav_variant = value < 0 ? d.trav_variant : value;
+	if (!strcmp(key, "trav_variant")) {
+		if (value >= 0 && value != 0 && value != 7 && value != 9 && value != 14 && value != 15)
+			return fail(PTX_E_INVALID, "ptx_ctx_tune: trav_variant %d is not in this build (0, 7, 9, 14, 15)", value);
+		ctx->trav_variant = value < 0 ? d.trav_variant : value;
+	}
 	else if (!strcmp(key, "trav_blocks")) ctx->trav_blocks_per_cu = value < 0 ? d.trav_blocks_per_cu : clampi(value, 1, 64);
 	else if (!strcmp(key, "wf_batch")) ctx->wf_batch = value < 0 ? d.wf_batch : clampi(value, 1, 256);
 	else if (!strcmp(key, "megakernel")) ctx->force_megakernel = value < 0 ? d.force_megakernel : value != 0;
@@ -185,7 +187,6 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "seg_mode")) ctx->seg_mode = value < 0 ? d.seg_mode : clampi(value, 0, 1);
 	else if (!strcmp(key, "seg_blocks")) ctx->seg_blocks_per_cu = value < 0 ? d.seg_blocks_per_cu : clampi(value, 1, 64);
 	else if (!strcmp(key, "wide_margin_ppm")) ctx->wide_margin_ppm = value < 0 ? d.wide_margin_ppm : clampi(value, 0, 1000000);
-	else if (!strcmp(key, "wide_cfg")) ctx->wide_cfg = value < 0 ? d.wide_cfg : value;
 	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
 	return PTX_OK;
@@ -981,7 +982,7 @@ extern "C" int ptx_accum_clear(PtxCtx* ctx) {
 
 // Division of n < 2^28 by a launch-uniform d in [2, 2^28] as mulhi(n, m) >> s: with L = ceil(log2 d) and k = 31 + L,
 // m = floor(2^k / d) + 1 < 2^32 and the error n (m d - 2^k) <= n d < 2^(28 + L) < 2^k, so the quotient is exact
-// (checked against n / d in ptx_render_samples for the launch's extreme n). d = 1 has no such pair: the kernel tests for it.
+// (wf_magic_check compares it with n / d for the launch's extreme n in ptx_render_samples). d = 1 has no such pair: the kernel tests for it.
 static void wf_magic_div(uint32_t d, uint32_t* m, uint32_t* s) {
 	if (d <= 1) { *m = 0; *s = 0; return; }
 	uint32_t L = 0;
@@ -989,6 +990,11 @@ static void wf_magic_div(uint32_t d, uint32_t* m, uint32_t* s) {
 	const uint32_t k = 31 + L;
 	*m = (uint32_t)((((uint64_t)1 << k) / d) + 1);
 	*s = k - 32;
+}
+
+static bool wf_magic_check(uint32_t n, uint32_t d, uint32_t m, uint32_t sh) {
+	if (d <= 1) return true;
+	return (uint32_t)((((uint64_t)n * m) >> 32) >> sh) == n / d;
 }
 
 static size_t stack_lds_bytes(const PtxScene* s) { return (size_t)s->dev.stack_entries * PT_BLOCK * sizeof(int); }
@@ -1001,100 +1007,53 @@ static int check_scene(const PtxCtx* ctx, const PtxScene* scene, const char* who
 }
 
 // One traversal launch of the wavefront pipeline: the rays queued for multi-node mesh `obj` (queue k).
+//   trav_variant 0 (default)  the wide traversal (pt_wide.h), then the exact kernel over its retry queue
+//                14           the same, counted by the wide kernel's own counting twin
+//                15           the exact kernel alone: wf_traverse_coop_kernel, leaf mode 9 = the reference's visiting order
+//                7, 9         the exact kernel with whole leaves per step (leaf modes 3, 4): what trees too deep for the LDS
+//                             areas of mode 9 fall back to; selectable so that the fall-backs are tested on ordinary scenes
+// (Rounds 1-2 carried thirteen more A/B variants - one ray per lane, leaf modes 0-2 and 5-8, the unified item loop, probe
+// builds of the wide kernel; their measurements are in DESIGN.md 3.2, their code is in the history.)
 static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams& wp, int obj, int k, int collect_stats) {
 	const int cus = ctx->cus;
-	const size_t tb = (size_t)cus * (size_t)ctx->trav_blocks_per_cu; // persistent waves, each owns queue/waves entries
+	const size_t tb = (size_t)cus * (size_t)ctx->trav_blocks_per_cu; // persistent waves, each claims queue chunks
 	const size_t lds = stack_lds_bytes(scene);
-#define TRAV(F, P, O, C) hipLaunchKernelGGL((wf_traverse_kernel<F, P, O, C>), dim3((unsigned)tb), dim3(PT_BLOCK), lds, ctx->stream, scene->dev, wp, obj, k)
+	// <stats, min waves/SIMD for the register allocator, queue chunk, descent threshold, leaf mode>
 #define COOP(F, O, C, A, T) hipLaunchKernelGGL((wf_traverse_coop_kernel<F, O, C, A, T>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + ((T) == 4 ? WF_STAGE_BYTES : (T) >= 5 ? WF_GRP_BYTES : 0), ctx->stream, scene->dev, wp, obj, k)
-	// Default: cooperative-leaf kernel <stats, min waves/SIMD for the register allocator, queue chunk,
-	// descent threshold, leaf mode>. Leaf modes (pt_wavefront.h):
-	//   9 = mode 6 with the four group boxes of a leaf read from their 48-B quantised form: 3 loads instead of 8  <- default
-	//   6 = mode 5 with the node records fetched by the quad through LDS (one L1 tag lookup per record)
-	//   5 = boxed groups of eight triangles inside the leaves: group boxes per lane, the touched
-	//       groups sixteen per step (needs WF_GRP_BYTES of LDS behind the stacks)
-	//   4 = whole leaves, four per step, two triangles per lane in packed FP32, rays handed over
-	//       through LDS and hits reduced with DPP (needs WF_STAGE_BYTES)
-	//   3 = the same step with the rays broadcast by shuffles and the hits folded one by one
-	//   1 = two leaves per step, branch-free scalar test; 0 = same with the early-exit test;
-	//   2 = mode 1 with two steps' loads in flight.
-	// Trees too deep for the LDS areas fall back to mode 3. PTX_TRAV_VARIANT / ptx_ctx_tune select
-	// the earlier designs for A/B runs (tools/sweep.sh); bench workload, 64-sample passes (Mrays/s):
-	//   0: 6750 (wide traversal, pt_wide.h, 128-sample passes; the other figures are 64-sample passes of round 1)   15: leaf mode 9 alone (3830)   13: leaf mode 6 (3690)   1: one ray per lane, static queue split (700 at 8-sample passes)   2: same, dynamic chunks
-	//   3: descent waits for every lane   4: early-exit test   5: two steps in flight (slower)
-	//   6: two leaves per step, scalar FP32 (1690)   7: leaf mode 3 (1890)   8: mode 4 at 4 waves/SIMD (1975)
-	//   9: mode 4 at 5 waves/SIMD (2008)   10: mode 5 with 64-entry chunks and descent threshold 32 (3090)   11: mode 5 (3150)
-#define UNI(F, O, C, U) hipLaunchKernelGGL((wf_traverse_unified_kernel<F, O, C, U>), dim3((unsigned)tb), dim3(PT_BLOCK), lds + WF_UNI_BYTES, ctx->stream, scene->dev, wp, obj, k)
-	//   12: unified item loop (pt_unified.h): descent and group boxes in one loop, units tested once 16 have gathered
-	//   0 / 14: wide traversal (pt_wide.h) + the exact kernel (leaf mode 9) over its retry queue; 14 counts with its own twin, 0 with the exact kernel
-	//   15: leaf mode 9 alone (the default before the wide traversal)
 	const int scap = scene->dev.wide_stack < ctx->wide_scap ? scene->dev.wide_stack : ctx->wide_scap;
 	const size_t wide_lds = (size_t)scap * PT_BLOCK * WFW_STACK_ENTRY_BYTES + WFW_BYTES;
-#define WIDEK(F, O, T, D, ...) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, O, WF_CHUNK, T, D, ##__VA_ARGS__>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap, 1.0f + 1e-6f * (float)ctx->wide_margin_ppm, 1e-6f * (float)ctx->wide_margin_ppm)
-	// <stats, waves/SIMD for the register allocator, -, lanes that must wait before a turn, units that must gather before a drain>
-#define WIDE(F) switch (ctx->wide_cfg) { \
-		case 1: WIDEK(F, 5, 8, 32, 4); break;    /* the first default: 5 waves, turn at 8, split refill */ \
-		case 2: WIDEK(F, 5, 8, 32); break; \
-		case 3: WIDEK(F, 6, 8, 32); break; \
-		case 4: WIDEK(F, 6, 24, 32); break; \
-		case 5: WIDEK(F, 6, 16, 48); break; \
-		case 6: WIDEK(F, 6, 16, 16); break; \
-		case 8: WIDEK(F, 6, WFW_TURN_MIN, WFW_DRAIN_MIN, 1); break;   /* sensitivity probe: + 24 VALU instructions per visit */ \
-		case 9: WIDEK(F, 6, WFW_TURN_MIN, WFW_DRAIN_MIN, 2); break;   /* sensitivity probe: + 1 load per visit */ \
-		default: WIDEK(F, 6, WFW_TURN_MIN, WFW_DRAIN_MIN); break; }
-	const bool uni_fits = lds + WF_UNI_BYTES <= 64 * 1024;
+	// <stats, waves/SIMD for the register allocator, queue chunk, lanes that must wait before a turn, units that must gather before a drain>
+#define WIDE(F) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, 6, WF_CHUNK, WFW_TURN_MIN, WFW_DRAIN_MIN>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap, 1.0f + 1e-6f * (float)ctx->wide_margin_ppm, 1e-6f * (float)ctx->wide_margin_ppm)
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
-	// the exact kernel for the rays the wide traversal could not decide (equal t from two leaves, stack overflow)
+	// the exact kernel in the best leaf mode the tree's stack leaves LDS for (or the one a test asks for)
+	auto exact = [&](const WfParams& wp, size_t tb, bool stats) {
+		const int mode = ctx->trav_variant == 7 ? 3 : ctx->trav_variant == 9 ? 4 : 9;
+		if (stats) {
+			if (mode == 9 && grp_fits) COOP(PT_F_STATS, 4, WF_CHUNK, WF_ATHRESH, 9);
+			else if (mode != 3 && stage_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
+			else COOP(PT_F_STATS, 4, 64, 32, 3);
+		} else {
+			if (mode == 9 && grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 9);
+			else if (mode != 3 && stage_fits) COOP(0, 5, 64, 32, 4);
+			else COOP(0, 4, 64, 32, 3);
+		}
+	};
+	// the rays the wide traversal could not decide (equal t from two leaves, stack overflow, fragile winner): few (bench
+	// scene: about 250 of 40 million), so one workgroup per CU; a full persistent grid costs 0.3 ms
 	auto exact_retry = [&]() {
 		WfParams wr = wp;
 		wr.use_retry = 1;
-		const WfParams& wp = wr;   // the launch macros name `wp`
-		// few rays (bench scene: about a dozen of 40 million): one workgroup per CU; a full persistent grid costs 0.3 ms
-		const size_t tb = (size_t)cus;
-		if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 9);
-		else if (stage_fits) COOP(0, 5, 64, 32, 4);
-		else COOP(0, 4, 64, 32, 3);
+		exact(wr, (size_t)cus, false);
 	};
+	const bool wide = ctx->trav_variant == 0 || ctx->trav_variant == 14;
 	if (collect_stats) {
 		if (ctx->trav_variant == 14) { WIDE(PT_F_STATS); exact_retry(); }
-		else if (ctx->trav_variant == 12 && uni_fits) UNI(PT_F_STATS, 5, 128, 16);
-		else if (ctx->trav_variant == 1 || ctx->trav_variant == 2) TRAV(PT_F_STATS, 1, 3, 64);
-		else if (ctx->trav_variant == 6) COOP(PT_F_STATS, 4, 64, 32, 1);
-		else if (ctx->trav_variant == 7 || !stage_fits) COOP(PT_F_STATS, 4, 64, 32, 3);
-		else if (ctx->trav_variant == 8 || ctx->trav_variant == 9 || !grp_fits) COOP(PT_F_STATS, 4, 64, 32, 4);
-		else if (ctx->trav_variant == 10 || ctx->trav_variant == 11) COOP(PT_F_STATS, 4, 128, 28, 5);
-		else if (ctx->trav_variant == 13) COOP(PT_F_STATS, 4, WF_CHUNK, WF_ATHRESH, 6);
-		else COOP(PT_F_STATS, 4, WF_CHUNK, WF_ATHRESH, 9);   // the counting twin of the default kernel
-	} else switch (ctx->trav_variant) {
-		case 1: TRAV(0, 1, 3, 0); break;
-		case 2: TRAV(0, 1, 3, 64); break;
-		case 3: COOP(0, 4, 64, 0, 3); break;
-		case 4: COOP(0, 3, 32, 32, 0); break;
-		case 5: COOP(0, 3, 32, 32, 2); break;
-		case 6: COOP(0, 7, 64, 32, 1); break;
-		case 7: COOP(0, 4, 64, 32, 3); break;
-		case 8: if (stage_fits) COOP(0, 4, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
-		case 9: if (stage_fits) COOP(0, 5, 64, 32, 4); else COOP(0, 4, 64, 32, 3); break;
-		case 10: if (grp_fits) COOP(0, 4, 64, 32, 5); else COOP(0, 4, 64, 32, 3); break;
-		case 11: if (grp_fits) COOP(0, 4, 128, 28, 5); else COOP(0, 4, 64, 32, 3); break;
-		case 13: if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 6); else COOP(0, 4, 64, 32, 3); break;
-		case 12: if (uni_fits) UNI(0, 5, 128, 16); else COOP(0, 4, 64, 32, 3); break;
-		case 15:
-			if (grp_fits) COOP(0, 4, WF_CHUNK, WF_ATHRESH, 9);
-			else if (stage_fits) COOP(0, 5, 64, 32, 4);
-			else COOP(0, 4, 64, 32, 3);
-			break;
-		default:
-			WIDE(0);
-			exact_retry();
-			break;
-	}
+		else exact(wp, tb, true);   // the reference's counters: the exact kernel's counting twin
+	} else if (wide) { WIDE(0); exact_retry(); }
+	else exact(wp, tb, false);
 #undef WIDE
-#undef WIDEK
-#undef TRAV
 #undef COOP
-#undef UNI
 }
 
 extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
@@ -1127,6 +1086,8 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	const int W = ctx->cam.width, Hh = ctx->cam.height;
 	const int tiles_x = (W + 7) / 8, tiles_y = (Hh + 7) / 8;
 	const size_t npt = (size_t)tiles_x * tiles_y * 64, npix = (size_t)W * Hh;
+	// path ids and their decomposition (multiply-high division, wf_magic_div) are proven for fewer than 2^28 paths per pass
+	if (npt > ((size_t)1 << 28)) return fail(PTX_E_LIMIT, "ptx_render_samples: %zu padded pixels per sample exceed the 2^28 paths of a pass", npt);
 	int batch = ctx->wf_batch;
 	while (batch > 1 && npt * (size_t)batch > ((size_t)1 << 28)) batch >>= 1;
 	if (batch > num_samples) batch = num_samples;
@@ -1159,6 +1120,9 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 		wf_magic_div((uint32_t)tiles_x, &wp.tx_m, &wp.tx_s);
 		wp.npix = (int)npix;
 		wp.n_total = (int)(npt * (size_t)b);
+		if (!wf_magic_check((uint32_t)wp.n_total - 1u, (uint32_t)npt, wp.npt_m, wp.npt_s) || !wf_magic_check((uint32_t)npt - 1u, (uint32_t)npt, wp.npt_m, wp.npt_s) ||
+		    !wf_magic_check((uint32_t)(npt >> 6) - 1u, (uint32_t)tiles_x, wp.tx_m, wp.tx_s) || !wf_magic_check((uint32_t)tiles_x, (uint32_t)tiles_x, wp.tx_m, wp.tx_s))
+			return fail(PTX_E_LIMIT, "ptx_render_samples: multiply-high division check failed (npt %zu, tiles_x %d)", npt, tiles_x);
 		wp.k0 = k0; wp.k1 = k1;
 		wp.num_big = scene->num_big;
 		wp.max_bounces = maxb;

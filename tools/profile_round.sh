@@ -1,11 +1,12 @@
-# Round-2 profile of the bench workload: one kernel-trace pass and separate PMC passes (one counter block per
-# run: rocprofv3 does not split counters over passes; no trace domain beside --pmc).
-# usage (on the GPU box, from the repo root): bash tools/profile_r02.sh [tag]     -> gpurun_out/prof_r02[_tag]/
+# Profile of the bench workload for one round: one kernel-trace pass and separate PMC passes (one counter block per run:
+# rocprofv3 does not split counters over passes; no trace domain beside --pmc), condensed into profiles/<tag>_*.
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh <tag, e.g. r03> <commit id>   -> gpurun_out/prof_<tag>/
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_r02${1:+_$1}
+T=${1:-r03}
+O=gpurun_out/prof_$T
 rm -rf $O; mkdir -p $O
-B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline"
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/trace.log 2>&1 || exit 1
+B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-strong-leg"
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg > $O/trace.log 2>&1 || exit 1
 echo trace done
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1 || exit 2
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1 || exit 3
@@ -16,4 +17,4 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_AN
 echo sq done
 timeout -s KILL 120 rocprofv3 --pmc TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_ACCESSES_sum GRBM_GUI_ACTIVE --output-format csv -d $O/ta -- $B > $O/ta.log 2>&1 || exit 7
 echo ta done
-python3 tools/summarize_r02.py $O
+python3 tools/summarize_round.py $O $T "${2:-unknown}" gpurun_out/profiles_$T

@@ -1,18 +1,44 @@
-"""Condense a tools/profile_r02.sh run into the two files bench.py and the reviewers read:
-    profiles/r02_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied as written)
-    profiles/r02_pmc.json           per-kernel PMC sums over the dispatches of ONE bench step + derived fractions
-usage: python tools/summarize_r02.py gpurun_out/prof_r02 [profiles]"""
-import collections, csv, glob, json, os, shutil, sys
+"""Condense a tools/profile_round.sh run into the two files bench.py and the reviewers read:
+    <dst>/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (copied as written)
+    <dst>/<tag>_pmc.json           per-kernel PMC sums over the dispatches of ONE bench step + derived fractions, stamped with
+                                   the commit id and a hash of the kernel sources, so bench.py can tell a stale file
+usage: python tools/summarize_round.py gpurun_out/prof_r03 r03 <commit id> [dst = profiles]"""
+import collections, csv, glob, hashlib, json, os, shutil, sys
 
-src = sys.argv[1]
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles"
+src, tag, commit = sys.argv[1], sys.argv[2], sys.argv[3]
+dst = sys.argv[4] if len(sys.argv) > 4 else "profiles"
 os.makedirs(dst, exist_ok=True)
-CUS, SIMDS = 256, 1024
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 
+
+def csrc_sha1():
+    """sha1 over the kernel sources and the build flags (the same function is in bench.py)"""
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "path-tracer_amd")
+    for f in sorted(glob.glob(os.path.join(base, "csrc", "*"))) + [os.path.join(base, "Makefile")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def device_units():
+    try:
+        import importlib, ctypes as C
+        sys.path.insert(0, ROOT)
+        pt = importlib.import_module("path-tracer_amd")
+        cu = C.c_int()
+        pt.check(pt.lib().ptx_device_info(0, None, 0, C.byref(cu), None, None))
+        return cu.value
+    except Exception:
+        return 256
+
+
+CUS = device_units()
+SIMDS = 4 * CUS
 stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
 avg_ns = {}
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, "r02_kernel_stats.csv"))
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
     for r in csv.DictReader(open(stats[0])):
         avg_ns[r["Name"].split("(")[0].replace("void ", "")] = (float(r["AverageNs"]), int(r["Calls"]))
 
@@ -28,10 +54,12 @@ for f in sorted(glob.glob(os.path.join(src, "*", "**", "*_counter_collection.csv
         disp[k][pass_name].add(r["Dispatch_Id"])
         sums[k]["_vgpr"] = float(r["VGPR_Count"]); sums[k]["_sgpr"] = float(r["SGPR_Count"]); sums[k]["_lds"] = float(r["LDS_Block_Size"])
 
-out = {"command": "tools/profile_r02.sh: rocprofv3 --pmc <one block per pass> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline; "
-                  "kernel_stats from rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline",
-       "note": "counter sums over the dispatches of one bench step (128 spp, 1920x1080 Lamborghini stand-in, real lp560 textures); "
-               "<1,...> kernels are the counting variants of bench.py's roofline leg. derived: see tools/summarize_r02.py",
+out = {"round": tag, "commit": commit, "csrc_sha1": csrc_sha1(), "compute_units": CUS,
+       "command": "tools/profile_round.sh: rocprofv3 --pmc <one block per pass> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-strong-leg; "
+                  "kernel_stats from rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg",
+       "note": "counter sums over the dispatches of one bench step (128 spp, 1920x1080 Lamborghini stand-in, real lp560 textures); keys are the "
+               "FULL kernel names incl. template arguments; <1,...> kernels are the counting variants of bench.py's roofline leg. "
+               "derived: see tools/summarize_round.py",
        "kernels": {}}
 for k, c in sums.items():
     n = max(len(v) for v in disp[k].values())
@@ -50,7 +78,6 @@ for k, c in sums.items():
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in c:
             d["l1_tag_lookups_per_cu_cycle"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / (CUS * cyc)
         if "SQ_ACTIVE_INST_VALU" in c:
-            # SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants): one per VALU instruction here.
             # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles (SIMD-32), 4 for a wave alone on its SIMD.
             d["valu_issue_frac_2cyc"] = c["SQ_INSTS_VALU"] * 2.0 / (SIMDS * cyc)
             d["valu_issue_frac_4cyc"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cyc)
@@ -58,6 +85,8 @@ for k, c in sums.items():
         d["active_lanes_per_valu_inst"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
     if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c:
         d["wave_time_waiting_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_WAVE_CYCLES") and g:
+        d["waves_per_simd"] = c["SQ_WAVE_CYCLES"] / (SIMDS * g / 8.0)   # SQ_WAVE_CYCLES counts wave-resident cycles (quad-cycle units cancel: see r02)
     if "TCC_HIT_sum" in c:
         d["l2_hit_frac"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -67,6 +96,6 @@ for k, c in sums.items():
         d["l1_to_l2_read_gbs"] = c["TCP_TCC_READ_REQ_sum"] * 64.0 / n / avg_ns[k][0]      # 64 B per request; B/ns = GB/s
     e["derived"] = d
     out["kernels"][k] = e
-json.dump(out, open(os.path.join(dst, "r02_pmc.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
 for k, e in out["kernels"].items():
     print(k, json.dumps({a: (round(b, 4) if isinstance(b, float) else b) for a, b in e["derived"].items()}))
