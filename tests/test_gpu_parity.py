@@ -151,7 +151,8 @@ def test_full_size_lamborghini_matches_oracle(pt, orc, ctx):
                 acc_g, st_g = gpuops.render(ctx, scene, cam, 3, 1, 7, stats=stats)
                 diff = np.nonzero((acc_o.view(np.uint32) != acc_g.view(np.uint32)).any(axis=1))[0]
                 assert len(diff) == 0, f"variant {variant} stats {stats}: {len(diff)} pixels differ, first {diff[:5]}"
-                keys = ("rays", "paths") if not stats else ("rays", "paths", "n_inner", "n_box", "n_tri", "n_sphere", "n_leaf", "hit_mesh", "hit_sphere",
+                # (variant 14 counts what the WIDE kernel executes, PtxStats.x_*, not the reference's node and triangle counters)
+                keys = ("rays", "paths") if not stats or variant == 14 else ("rays", "paths", "n_inner", "n_box", "n_tri", "n_sphere", "n_leaf", "hit_mesh", "hit_sphere",
                                                             "hit_textured", "trav_rays", "trav_inner", "trav_box", "trav_tri", "trav_leaf")
                 for k in keys:
                     assert getattr(st_o, k) == getattr(st_g, k), f"variant {variant}: counter {k}: oracle {getattr(st_o, k)} gpu {getattr(st_g, k)}"
