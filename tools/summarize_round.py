@@ -86,7 +86,7 @@ for k, c in sums.items():
     if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c:
         d["wave_time_waiting_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
     if c.get("SQ_WAVE_CYCLES") and g:
-        d["waves_per_simd"] = c["SQ_WAVE_CYCLES"] / (SIMDS * g / 8.0)   # SQ_WAVE_CYCLES counts wave-resident cycles (quad-cycle units cancel: see r02)
+        d["waves_per_simd"] = 4.0 * c["SQ_WAVE_CYCLES"] / (SIMDS * g / 8.0)   # SQ_WAVE_CYCLES counts wave-resident QUAD-cycles (MI355X_MICROARCH.md); average over the launch incl. ramp and tail
     if "TCC_HIT_sum" in c:
         d["l2_hit_frac"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
