@@ -238,6 +238,53 @@ def test_production_rays_default_and_exact_traversal_accumulate_identically(pt, 
         _tune(pt, ctx, b"trav_variant", -1)
 
 
+@pytest.mark.parametrize("grp_mode", [1, 0])
+def test_unevenly_tessellated_mesh_matches_the_oracle(pt, orc, ctx, tmp_path, grp_mode):
+    """The headline stand-in is evenly tessellated. tools/uneven_mesh.py is its opposite: panels with edges of 2-4 units, 300
+    slivers of 4 x 0.006, 40 blobs with edges of ~0.02 (100:1 in edge length, 10^4:1 in area), 1500 needles of aspect 100:1;
+    diffuse, glossy and glass materials. Render and ray-by-ray hits equal the oracle through the default traversal, its
+    counting twin and the exact kernel, for both ways of cutting leaves into groups (grp_mode: bisection / strips)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("uneven_mesh", os.path.join(os.path.dirname(__file__), "..", "tools", "uneven_mesh.py"))
+    um = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(um)
+    path, ntri = um.write_scene(str(tmp_path))
+    try:
+        _tune(pt, ctx, b"grp_mode", grp_mode)
+        desc, cam = pt.load_scene(path)
+        assert desc.contents.num_triangles == ntri and desc.contents.num_nodes > 1000
+        scene = pt.host().pth_scene_device()
+        gpuops.render_init(ctx, cam)
+        acc_o, st_o = orc.render(desc, cam, 0, 8, 5)
+        assert st_o.hit_mesh > 10000
+        rng = np.random.default_rng(9)
+        o1, d1 = orc.generate_rays(cam, 2, 5)
+        o2 = rng.uniform([-2.2, -0.2, -1.2], [2.2, 1.4, 1.2], (40000, 3)).astype(np.float32)
+        d2 = rng.normal(size=(40000, 3))
+        d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+        # rays ALONG the slivers and panels (in-plane directions a hair above them)
+        o3 = np.stack([rng.uniform(-1.9, 1.9, 20000), 0.4 + rng.uniform(-1e-4, 1e-4, 20000), rng.uniform(-1, 1, 20000)], 1).astype(np.float32)
+        d3 = np.stack([rng.normal(size=20000), rng.normal(scale=1e-4, size=20000), rng.normal(size=20000)], 1)
+        d3 = (d3 / np.linalg.norm(d3, axis=1, keepdims=True)).astype(np.float32)
+        o, dd = np.concatenate([o1, o2, o3]), np.concatenate([d1, d2, d3])
+        obj = 2
+        ho = orc.trace(desc, o, dd, obj)
+        assert (ho["hit"] == 1).sum() > 20000
+        for variant in (0, 14, 15):
+            _tune(pt, ctx, b"trav_variant", variant)
+            acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 8, 5)
+            bad = np.nonzero((acc_o.view(np.uint32) != acc_g.view(np.uint32)).any(axis=1))[0]
+            assert len(bad) == 0, f"grp_mode {grp_mode} variant {variant}: {len(bad)} pixels differ, first {bad[:5]}"
+            assert st_o.rays == st_g.rays
+            hq = gpuops.trace_queued(ctx, scene, o, dd, obj)
+            for k in ("object", "prim", "t_bits", "bary"):
+                badr = np.nonzero((ho[k] != hq[k]).reshape(len(o), -1).any(axis=1))[0]
+                assert len(badr) == 0, f"grp_mode {grp_mode} variant {variant}: {k} differs for {len(badr)} rays, first {badr[:5]}"
+    finally:
+        _tune(pt, ctx, b"trav_variant", -1)
+        _tune(pt, ctx, b"grp_mode", -1)
+
+
 @pytest.mark.parametrize("seed", list(range(11, 27)))
 def test_random_soups_render_like_the_oracle(pt, orc, ctx, tmp_path, seed):
     """Fuzz: triangle soups of random size, density and triangle shape (needles and slivers included), a random
