@@ -201,6 +201,9 @@ int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* desc, PtxScene** out);
 /* reference: src/world_load.cpp:553-574 freeWorldObjects */
 int ptx_scene_free(PtxCtx* ctx, PtxScene* scene);
 int64_t ptx_scene_device_bytes(const PtxScene* scene);
+/* Diagnostics (no reference counterpart): how many multi-node meshes of the scene got the surface-area-heuristic wide tree
+ * instead of the one collapsed from the reference's KD tree (ptx_ctx_tune "wide_build"; results do not depend on it). */
+int ptx_scene_wide_sah_objects(const PtxScene* scene);
 
 /* ---- render -------------------------------------------------------------------------------
  * reference: src/kernel.cu:22-28 kernelInit + src/pathtracing.cu:44-62 initPathTracing.
@@ -245,10 +248,14 @@ int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches,
  *                     node-by-node visiting order, src/intersect.cuh:119-212)
  *   "wide_margin_ppm" margin of the wide traversal's distance culling, parts per million (default 10000 = 1 %)
  *   "wide_scap"       stack entries per lane of the wide traversal (default 10; rays that need more go to the exact kernel)
- *   "wide_cfg"        A/B configurations of the wide kernel (waves per SIMD, turn / drain thresholds)
+ *   "wide_build"      which 4-wide tree a multi-node mesh gets at the NEXT ptx_scene_upload: 0 (default) the cheaper, by modelled
+ *                     cost, of 1 = the tree collapsed from the reference's KD tree and 2 = one built by the surface-area heuristic
+ *   "seg_mode"        1 (default) segment kernel with the bounce loop inside the launch (pt_segloop.h), 0 = one bounce per launch
+ *   "seg_blocks"      workgroups per CU of the segment launches
  *   "grp_mode", "grp_pad_ppm"  how leaf triangles are cut into groups of eight and how far their boxes are padded (parts per
  *                     million of the mesh diagonal, on top of 5e-5); read by the NEXT ptx_scene_upload
- *   "seg_lds_tables"  material / texture-descriptor tables of the segment kernel in LDS (default 1)
+ *   "seg_lds_tables"  material / texture-descriptor tables of the segment kernel in LDS: 0 never, 1 (default) for the per-bounce kernel only
+ *                     (the bounce-loop kernel would lose its fifth wave per SIMD to them), 2 for both
  *   "trav_blocks"     persistent workgroups per CU;  "wf_batch"  samples per wavefront pass (1..256, default 128)
  *   "megakernel"      1 = one-lane-per-pixel kernel instead of the wavefront pipeline
  * WHAT CAN CHANGE A RESULT: nothing but "trav_variant" 0 / 14 together with "wide_margin_ppm", and only on rays at grazing
@@ -257,7 +264,7 @@ int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches,
  * on the headline mesh, 0 pixels of the headline frame at 1000 spp (tests/test_gpu_wide.py). "trav_variant"
  * 15 reproduces the reference on those too. Every other knob only reschedules work; the parity tests run the variants
  * against each other. Defaults come from the environment (PTX_TRAV_VARIANT, PTX_WIDE_MARGIN_PPM, PTX_WIDE_SCAP,
- * PTX_WIDE_CFG, PTX_GRP_MODE, PTX_GRP_PAD_PPM, PTX_SEG_LDS_TABLES, PTX_TRAV_BLOCKS, PTX_WF_BATCH, PTX_MEGAKERNEL) at
+ * PTX_WIDE_BUILD, PTX_SEG_MODE, PTX_SEG_BLOCKS, PTX_GRP_MODE, PTX_GRP_PAD_PPM, PTX_SEG_LDS_TABLES, PTX_TRAV_BLOCKS, PTX_WF_BATCH, PTX_MEGAKERNEL) at
  * ptx_ctx_create; value < 0 restores that default. */
 int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value);
 /* HIP-event timer on the context's stream (for bench.py's roofline leg). */

@@ -98,7 +98,7 @@ class PtxBsdfCase(C.Structure):
 # Every symbol include/ptx_hip.h declares (the "not gpu" tests check that the library exports all of them).
 PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_device_info", "ptx_ctx_create", "ptx_ctx_destroy",
-    "ptx_scene_upload", "ptx_scene_free", "ptx_scene_device_bytes", "ptx_render_init", "ptx_render_set_camera",
+    "ptx_scene_upload", "ptx_scene_free", "ptx_scene_device_bytes", "ptx_scene_wide_sah_objects", "ptx_render_init", "ptx_render_set_camera",
     "ptx_render_cleanup", "ptx_accum_clear", "ptx_render_samples", "ptx_render_sync", "ptx_accum_device_ptr",
     "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_stats_get", "ptx_stats_reset",
     "ptx_wavefront_counts", "ptx_ctx_tune", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_trace_rays_queued", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample", "ptx_selftest_rcp", "ptx_selftest_vec3",

@@ -58,7 +58,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
-	int wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu;
+	int wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu, wide_build;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -73,6 +73,7 @@ struct PtxScene {
 	int max_depth;
 	int num_dev_triangles;
 	int num_big;                       // meshes with inner nodes
+	int wide_sah_objects;              // of them: meshes whose wide tree is the surface-area-heuristic candidate
 	int big_object[PT_MAX_BIG];        // their object indices, by queue slot
 };
 
@@ -123,7 +124,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu, wide_build;
 	bool force_megakernel;
 };
 
@@ -152,6 +153,7 @@ static Tuning tuning_defaults() {
 	// margin of the wide traversal's distance culling, relative to the best t (and absolute), in parts per million (pt_wide.h)
 	t.wide_margin_ppm = clampi(env_int("PTX_WIDE_MARGIN_PPM", 10000), 0, 1000000);
 	t.wide_scap = clampi(env_int("PTX_WIDE_SCAP", WFW_SCAP_MAX), 1, 32);
+	t.wide_build = clampi(env_int("PTX_WIDE_BUILD", 0), 0, 2);   // which wide tree a mesh gets: read at scene upload
 	return t;
 }
 
@@ -168,6 +170,7 @@ static void tune_defaults(PtxCtx* c) {
 	c->seg_mode = t.seg_mode;
 	c->seg_blocks_per_cu = t.seg_blocks_per_cu;
 	c->wide_scap = t.wide_scap;
+	c->wide_build = t.wide_build;
 }
 
 extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
@@ -188,6 +191,7 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "seg_blocks")) ctx->seg_blocks_per_cu = value < 0 ? d.seg_blocks_per_cu : clampi(value, 1, 64);
 	else if (!strcmp(key, "wide_margin_ppm")) ctx->wide_margin_ppm = value < 0 ? d.wide_margin_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
+	else if (!strcmp(key, "wide_build")) ctx->wide_build = value < 0 ? d.wide_build : clampi(value, 0, 2);
 	else return fail(PTX_E_INVALID, "ptx_ctx_tune: unknown key '%s'", key);
 	return PTX_OK;
 }
@@ -351,7 +355,7 @@ static void quantise_boxes4(const float lo[4][3], const float hi[4][3], const bo
 // padding), stored in the 8-bit form of grp_qbox. Leaves of more than four groups get intermediate nodes over
 // contiguous quarters of their (sorted) group list.
 struct WideItem {
-	int kind;        // 0 = KD node (scene-global index), 1 = run of `n` consecutive groups from global group `a`
+	int kind;        // 0 = KD node (scene-global index), 1 = run of `n` consecutive groups from global group `a`, 2 = node `a` of the SAH tree
 	int a, n;
 	float lo[3], hi[3];
 };
@@ -363,6 +367,11 @@ struct WideBuilder {
 	std::vector<float> kd_box;              // per KD node of the object: 6 floats, filled bottom-up
 	int base = 0;                           // first KD node of the object
 	int max_stack = 0;                      // most stack entries a traversal can hold at once (one per node with two or more inner children)
+	double cost = 0.0;                      // sum of the surfaces of all emitted nodes' child boxes: ~ box tests per random ray x root surface
+	// second candidate: a binary tree over the object's groups built top-down by the surface-area heuristic (16 bins per axis
+	// on the centres of the group boxes); leaves are single groups
+	struct BinNode { float lo[3], hi[3]; int left, right, group; };
+	std::vector<BinNode> bin;
 
 	static float area(const WideItem& it) {
 		const float dx = it.hi[0] - it.lo[0], dy = it.hi[1] - it.lo[1], dz = it.hi[2] - it.lo[2];
@@ -433,12 +442,118 @@ struct WideBuilder {
 		for (int k = 0; k < 3; ++k) { it.lo[k] = b[k]; it.hi[k] = b[3 + k]; }
 		return it;
 	}
+	// every group of the object, in leaf order
+	void object_groups(int root, std::vector<int>& ids) const {
+		std::vector<int> todo(1, root);
+		while (!todo.empty()) {
+			const int ni = todo.back();
+			todo.pop_back();
+			if (ni < 0) continue;
+			const float4* r = &nodes[(size_t)ni * 4];
+			if (kd_is_leaf(ni)) { const int g0 = 4 * as_int(r[0].x), ng = leaf_groups(r); for (int g = 0; g < ng; ++g) ids.push_back(g0 + g); continue; }
+			todo.push_back(as_int(r[3].y));
+			todo.push_back(as_int(r[3].x));
+		}
+	}
+	static float box_area(const float lo[3], const float hi[3]) {
+		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+		return dx * dy + dy * dz + dz * dx;
+	}
+	int build_sah(std::vector<int>& ids, int first, int last) {   // ids[first, last) -> index of the subtree's node in `bin`
+		BinNode nd;
+		nd.left = nd.right = nd.group = -1;
+		float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+		for (int k = 0; k < 3; ++k) { nd.lo[k] = INFINITY; nd.hi[k] = -INFINITY; }
+		for (int i = first; i < last; ++i) {
+			float lo[3], hi[3];
+			group_box(ids[(size_t)i], lo, hi);
+			for (int k = 0; k < 3; ++k) {
+				if (lo[k] < nd.lo[k]) nd.lo[k] = lo[k];
+				if (hi[k] > nd.hi[k]) nd.hi[k] = hi[k];
+				const float c = 0.5f * (lo[k] + hi[k]);
+				if (c < clo[k]) clo[k] = c;
+				if (c > chi[k]) chi[k] = c;
+			}
+		}
+		const int me = (int)bin.size();
+		if (last - first == 1) { nd.group = ids[(size_t)first]; bin.push_back(nd); return me; }
+		bin.push_back(nd);
+		const int NB = 16;
+		int best_axis = -1, best_cut = 0;
+		double best = 1e300;
+		for (int ax = 0; ax < 3; ++ax) {
+			const float ext = chi[ax] - clo[ax];
+			if (!(ext > 0.0f)) continue;
+			int cnt[NB];
+			float blo[NB][3], bhi[NB][3];
+			for (int b = 0; b < NB; ++b) { cnt[b] = 0; for (int k = 0; k < 3; ++k) { blo[b][k] = INFINITY; bhi[b][k] = -INFINITY; } }
+			for (int i = first; i < last; ++i) {
+				float lo[3], hi[3];
+				group_box(ids[(size_t)i], lo, hi);
+				int b = (int)((0.5f * (lo[ax] + hi[ax]) - clo[ax]) / ext * (float)NB);
+				b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+				cnt[b]++;
+				for (int k = 0; k < 3; ++k) { if (lo[k] < blo[b][k]) blo[b][k] = lo[k]; if (hi[k] > bhi[b][k]) bhi[b][k] = hi[k]; }
+			}
+			// sweep from the right, then from the left
+			float rarea[NB];
+			int rcnt[NB];
+			float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+			int c = 0;
+			for (int b = NB - 1; b >= 1; --b) {
+				for (int k = 0; k < 3; ++k) { if (blo[b][k] < lo[k]) lo[k] = blo[b][k]; if (bhi[b][k] > hi[k]) hi[k] = bhi[b][k]; }
+				c += cnt[b];
+				rcnt[b] = c;
+				rarea[b] = c ? box_area(lo, hi) : 0.0f;
+			}
+			for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+			c = 0;
+			for (int b = 0; b < NB - 1; ++b) {   // cut between bin b and b + 1
+				for (int k = 0; k < 3; ++k) { if (blo[b][k] < lo[k]) lo[k] = blo[b][k]; if (bhi[b][k] > hi[k]) hi[k] = bhi[b][k]; }
+				c += cnt[b];
+				if (c == 0 || rcnt[b + 1] == 0) continue;
+				const double sah = (double)box_area(lo, hi) * c + (double)rarea[b + 1] * rcnt[b + 1];
+				if (sah < best) { best = sah; best_axis = ax; best_cut = b; }
+			}
+		}
+		int mid;
+		if (best_axis < 0) mid = first + (last - first) / 2;   // all centres coincide: halve the list
+		else {
+			const float ext = chi[best_axis] - clo[best_axis];
+			const int ax = best_axis, cut = best_cut;
+			const float c0 = clo[ax];
+			std::vector<int>::iterator it = std::stable_partition(ids.begin() + first, ids.begin() + last, [&](int g) {
+				float lo[3], hi[3];
+				group_box(g, lo, hi);
+				int b = (int)((0.5f * (lo[ax] + hi[ax]) - c0) / ext * (float)NB);
+				b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+				return b <= cut;
+			});
+			mid = (int)(it - ids.begin());
+			if (mid == first || mid == last) mid = first + (last - first) / 2;
+		}
+		const int l = build_sah(ids, first, mid);
+		const int r = build_sah(ids, mid, last);
+		bin[(size_t)me].left = l;
+		bin[(size_t)me].right = r;
+		return me;
+	}
+	WideItem bin_item(int bi) const {
+		const BinNode& nd = bin[(size_t)bi];
+		if (nd.group >= 0) return run_item(nd.group, 1);
+		WideItem it; it.kind = 2; it.a = bi; it.n = 0;
+		for (int k = 0; k < 3; ++k) { it.lo[k] = nd.lo[k]; it.hi[k] = nd.hi[k]; }
+		return it;
+	}
 	static bool is_empty(const WideItem& it) { return it.kind == 1 && it.n == 0; }
 	static bool is_group(const WideItem& it) { return it.kind == 1 && it.n == 1; }
 	// the children of an item that is not a single group (2..4 of them)
 	void children(const WideItem& it, std::vector<WideItem>& ch) const {
 		ch.clear();
-		if (it.kind == 0) {
+		if (it.kind == 2) {
+			ch.push_back(bin_item(bin[(size_t)it.a].left));
+			ch.push_back(bin_item(bin[(size_t)it.a].right));
+		} else if (it.kind == 0) {
 			const float4* r = &nodes[(size_t)it.a * 4];
 			const WideItem l = kd_item(as_int(r[3].x)), rr = kd_item(as_int(r[3].y));
 			if (!is_empty(l)) ch.push_back(l);
@@ -485,6 +600,7 @@ struct WideBuilder {
 		int32_t ref[4] = {-1, -1, -1, -1};
 		for (size_t i = 0; i < list.size(); ++i) {
 			used[i] = true;
+			cost += (double)area(list[i]);
 			for (int k = 0; k < 3; ++k) { lo[i][k] = list[i].lo[k]; hi[i][k] = list[i].hi[k]; }
 			if (is_group(list[i])) ref[i] = (int32_t)(0x80000000u | (uint32_t)list[i].a);
 			else { ref[i] = first + (int)i; children(list[i], ch); emit(first + (int)i, ch, below); }
@@ -816,19 +932,58 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	// Wide trees (pt_scene.h, wide_nodes): one per multi-node mesh, roots per object
 	std::vector<float4> wide;
 	std::vector<int32_t> wide_root((size_t)(d->num_objects > 0 ? d->num_objects : 1), -1);
-	int wide_stack = 1;
+	int wide_stack = 1, wide_sah_objects = 0;
 	for (int oi = 0; oi < d->num_objects; ++oi) {
 		const DevObject& dv = objs[(size_t)oi];
 		if (dv.type != PTX_OBJ_MESH || dv.root_node < 0) continue;
-		WideBuilder wb{nodes, grp_boxes, wide};
-		wb.base = dv.first_node;
-		wb.fill_boxes(dv.root_node, d->objects[oi].num_nodes);
-		const WideItem root = wb.kd_item(dv.root_node);
-		std::vector<WideItem> top;
-		if (WideBuilder::is_group(root)) top.push_back(root);
-		else if (!WideBuilder::is_empty(root)) wb.children(root, top);
-		wide_root[(size_t)oi] = wb.emit_root(top);
-		if (wb.max_stack > wide_stack) wide_stack = wb.max_stack;
+		// two candidates, each built into its own array: the tree collapsed from the reference's median-split KD tree, and one
+		// built over the same groups by the surface-area heuristic. The modelled cost (sum of child-box surfaces = expected box
+		// tests of a random ray) picks; the collapsed tree keeps a 10 % bonus: on the evenly tessellated car the SAH tree has 4 %
+		// fewer node visits but 5 % more triangle units and is 1 % slower, on unevenly tessellated meshes it wins by a wide margin
+		// (tools/uneven_bench.py). ptx_ctx_tune "wide_build": 0 = choose (default), 1 = collapsed, 2 = surface-area heuristic.
+		std::vector<float4> cand[2];
+		int cand_root[2] = {-1, -1}, cand_stack[2] = {0, 0};
+		double cand_cost[2] = {1e300, 1e300};
+		for (int which = 0; which < 2; ++which) {
+			if ((ctx->wide_build == 1 && which == 1) || (ctx->wide_build == 2 && which == 0)) continue;
+			WideBuilder wb{nodes, grp_boxes, cand[which]};
+			wb.base = dv.first_node;
+			std::vector<WideItem> top;
+			if (which == 0) {
+				wb.fill_boxes(dv.root_node, d->objects[oi].num_nodes);
+				const WideItem root = wb.kd_item(dv.root_node);
+				if (WideBuilder::is_group(root)) top.push_back(root);
+				else if (!WideBuilder::is_empty(root)) wb.children(root, top);
+			} else {
+				std::vector<int> ids;
+				wb.object_groups(dv.root_node, ids);
+				if (ids.size() == 1) top.push_back(wb.run_item(ids[0], 1));
+				else if (ids.size() > 1) {
+					const WideItem root = wb.bin_item(wb.build_sah(ids, 0, (int)ids.size()));
+					wb.children(root, top);
+				}
+			}
+			cand_root[which] = wb.emit_root(top);
+			cand_stack[which] = wb.max_stack;
+			cand_cost[which] = wb.cost;
+		}
+		int use = cand_root[0] < 0 ? 1 : (cand_root[1] < 0 ? 0 : (cand_cost[1] < 0.9 * cand_cost[0] ? 1 : 0));
+		// rays that need more stack entries than a lane has (WFW_SCAP_MAX) go to the exact kernel: rare on either tree of the test
+		// meshes (0 and 1400 of 10^8 traversals), but a degenerate chain would send most rays there: then prefer the tree that fits
+		if (cand_root[0] >= 0 && cand_root[1] >= 0 && cand_stack[use] > 3 * WFW_SCAP_MAX && cand_stack[use ^ 1] <= 3 * WFW_SCAP_MAX) use ^= 1;
+		if (getenv("PTX_WIDE_BUILD_VERBOSE"))
+			fprintf(stderr, "object %d: wide tree cost collapsed %.4g (stack %d), surface-area heuristic %.4g (stack %d) -> %s\n", oi, cand_cost[0], cand_stack[0],
+			        cand_cost[1], cand_stack[1], use ? "surface-area heuristic" : "collapsed");
+		const int offset = (int)(wide.size() / 4);
+		for (size_t n = 0; n < cand[use].size() / 4; ++n) {   // links to nodes are indices into the candidate's own array
+			float4& links = cand[use][n * 4 + 3];
+			float* lf = &links.x;
+			for (int c = 0; c < 4; ++c) { const int32_t r = as_int(lf[c]); if (r >= 0) lf[c] = as_float(r + offset); }
+		}
+		wide.insert(wide.end(), cand[use].begin(), cand[use].end());
+		wide_root[(size_t)oi] = cand_root[use] + offset;
+		if (cand_stack[use] > wide_stack) wide_stack = cand_stack[use];
+		wide_sah_objects += use;
 	}
 	if (wide.empty()) wide.assign(4, make_float4(0, 0, 0, 0));
 	if (wide.size() / 4 >= ((size_t)1 << 24)) return fail(PTX_E_LIMIT, "scene has %zu wide nodes; the limit is 2^24", wide.size() / 4);
@@ -897,6 +1052,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	s->dev.stack_entries = scene_max_depth < 1 ? 1 : scene_max_depth;
 	s->dev.half_base = (int32_t)half_base;
 	s->dev.wide_stack = wide_stack;
+	s->wide_sah_objects = wide_sah_objects;
 	s->dev.num_materials = d->num_materials;
 	s->dev.num_textures = d->num_textures;
 	hipError_t e = hipStreamSynchronize(ctx->stream); // host vectors die at return
@@ -914,6 +1070,7 @@ extern "C" int ptx_scene_free(PtxCtx* ctx, PtxScene* scene) {
 }
 
 extern "C" int64_t ptx_scene_device_bytes(const PtxScene* scene) { return scene ? scene->bytes : 0; }
+extern "C" int ptx_scene_wide_sah_objects(const PtxScene* scene) { return scene ? scene->wide_sah_objects : 0; }
 
 // ---- render -----------------------------------------------------------------------------------
 

@@ -238,12 +238,14 @@ def test_production_rays_default_and_exact_traversal_accumulate_identically(pt, 
         _tune(pt, ctx, b"trav_variant", -1)
 
 
-@pytest.mark.parametrize("grp_mode", [1, 0])
-def test_unevenly_tessellated_mesh_matches_the_oracle(pt, orc, ctx, tmp_path, grp_mode):
+@pytest.mark.parametrize("grp_mode,wide_build", [(1, 0), (0, 0), (1, 1), (1, 2)])
+def test_unevenly_tessellated_mesh_matches_the_oracle(pt, orc, ctx, tmp_path, grp_mode, wide_build):
     """The headline stand-in is evenly tessellated. tools/uneven_mesh.py is its opposite: panels with edges of 2-4 units, 300
     slivers of 4 x 0.006, 40 blobs with edges of ~0.02 (100:1 in edge length, 10^4:1 in area), 1500 needles of aspect 100:1;
     diffuse, glossy and glass materials. Render and ray-by-ray hits equal the oracle through the default traversal, its
-    counting twin and the exact kernel, for both ways of cutting leaves into groups (grp_mode: bisection / strips)."""
+    counting twin and the exact kernel, for both ways of cutting leaves into groups (grp_mode: bisection / strips) and for both
+    candidates of the wide tree (wide_build 1 = collapsed from the reference's KD tree, 2 = surface-area heuristic; 0 = the
+    library's choice, which on this mesh is the latter: 32 instead of 58 node visits per traversal)."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("uneven_mesh", os.path.join(os.path.dirname(__file__), "..", "tools", "uneven_mesh.py"))
     um = importlib.util.module_from_spec(spec)
@@ -251,9 +253,12 @@ def test_unevenly_tessellated_mesh_matches_the_oracle(pt, orc, ctx, tmp_path, gr
     path, ntri = um.write_scene(str(tmp_path))
     try:
         _tune(pt, ctx, b"grp_mode", grp_mode)
+        _tune(pt, ctx, b"wide_build", wide_build)
         desc, cam = pt.load_scene(path)
         assert desc.contents.num_triangles == ntri and desc.contents.num_nodes > 1000
         scene = pt.host().pth_scene_device()
+        pt.lib().ptx_scene_wide_sah_objects.argtypes = [C.c_void_p]
+        assert pt.lib().ptx_scene_wide_sah_objects(scene) == (0 if wide_build == 1 else 1)
         gpuops.render_init(ctx, cam)
         acc_o, st_o = orc.render(desc, cam, 0, 8, 5)
         assert st_o.hit_mesh > 10000
@@ -283,6 +288,7 @@ def test_unevenly_tessellated_mesh_matches_the_oracle(pt, orc, ctx, tmp_path, gr
     finally:
         _tune(pt, ctx, b"trav_variant", -1)
         _tune(pt, ctx, b"grp_mode", -1)
+        _tune(pt, ctx, b"wide_build", -1)
 
 
 @pytest.mark.parametrize("seed", list(range(11, 27)))
