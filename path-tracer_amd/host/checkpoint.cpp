@@ -1,4 +1,5 @@
 #include "checkpoint.h"
+#include "camera.h"
 #include "../../include/ptx_hip.h"
 
 #include <cstddef>
@@ -22,12 +23,28 @@ uint64_t sceneContentHash(const PtxSceneDesc& d) {
 	if (d.triangles) fnv(h, d.triangles, sizeof(PtxTriangle) * (size_t)d.num_triangles);
 	if (d.nodes) fnv(h, d.nodes, sizeof(PtxKDNode) * (size_t)d.num_nodes);
 	if (d.leaf_tris) fnv(h, d.leaf_tris, sizeof(int32_t) * (size_t)d.num_leaf_tris);
-	for (int i = 0; i < d.num_textures; ++i) { fnv(h, &d.textures[i].width, 4); fnv(h, &d.textures[i].height, 4); }
+	for (int i = 0; i < d.num_textures; ++i) {
+		fnv(h, &d.textures[i].width, 4); fnv(h, &d.textures[i].height, 4);
+		// every 61st texel (the headline's textures are 252 MB of floats; a swapped or re-encoded file changes far more than one in 61)
+		const size_t n = (size_t)d.textures[i].width * (size_t)d.textures[i].height;
+		if (d.textures[i].rgba) for (size_t t = 0; t < n; t += 61) fnv(h, d.textures[i].rgba + 4 * t, 16);
+	}
 	return h ? h : 1;   // 0 means "not recorded"
 }
 
+uint64_t renderContentHash(const PtxSceneDesc& d, const Camera& cam) {
+	uint64_t h = sceneContentHash(d);
+	const float f[] = {cam.position.x, cam.position.y, cam.position.z, cam.direction.x, cam.direction.y, cam.direction.z, cam.up.x, cam.up.y, cam.up.z,
+	                   cam.right.x, cam.right.y, cam.right.z, cam.projection.pixel_size.x, cam.projection.pixel_size.y, cam.projection.screen_halfsize.x,
+	                   cam.projection.screen_halfsize.y, cam.projection.screen_dist, cam.projection.aa_jitter};
+	const int32_t i[] = {cam.projection.width, cam.projection.height, cam.preview_mode ? 1 : 0, cam.aabb_mode ? 1 : 0};
+	fnv(h, f, sizeof(f));
+	fnv(h, i, sizeof(i));
+	return h ? h : 1;
+}
+
 std::string checkpointMismatch(const AccumCheckpoint& ck, uint64_t scene_hash, int max_ray_bounces, int texture_enabled) {
-	if (ck.scene_hash != 0 && scene_hash != 0 && ck.scene_hash != scene_hash) return "it was rendered from a different scene";
+	if (ck.scene_hash != 0 && scene_hash != 0 && ck.scene_hash != scene_hash) return "it was rendered from a different scene, textures or camera";
 	if (ck.max_ray_bounces >= 0 && ck.max_ray_bounces != max_ray_bounces)
 		return "it was rendered with max_ray_bounces " + std::to_string(ck.max_ray_bounces) + ", not " + std::to_string(max_ray_bounces);
 	if (ck.texture_enabled >= 0 && ck.texture_enabled != (texture_enabled ? 1 : 0))

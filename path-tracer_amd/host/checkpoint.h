@@ -22,8 +22,14 @@ struct AccumCheckpoint {
 	std::vector<float> rgba;   // width * height * 4
 };
 
-// FNV-1a over the geometry, tree, materials and texture sizes of a flat scene description (include/ptx_hip.h)
+struct Camera;
+
+// FNV-1a over the geometry, tree, materials and textures (sizes and every 61st texel) of a flat scene description (include/ptx_hip.h)
 uint64_t sceneContentHash(const PtxSceneDesc& d);
+// The same scene seen by another camera is another image: sceneContentHash folded with what a sample depends on of the camera
+// (pose, projection, jitter width, preview / AABB switches; not gamma, which only the display uses). This is what a
+// checkpoint records as scene_hash (a resume with a moved camera used to mix two images silently).
+uint64_t renderContentHash(const PtxSceneDesc& d, const Camera& cam);
 // Empty string if `ck` continues a render of (scene_hash, bounces, textures); else what differs.
 std::string checkpointMismatch(const AccumCheckpoint& ck, uint64_t scene_hash, int max_ray_bounces, int texture_enabled);
 

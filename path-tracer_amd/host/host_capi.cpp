@@ -261,7 +261,7 @@ extern "C" int pth_checkpoint_save(const char* path, int samples_done) {
 	ck.height = sc.camera.projection.height;
 	ck.samples_done = samples_done;
 	ck.seed = kernelSeed();
-	ck.scene_hash = sceneContentHash(hostSceneFlat().desc);
+	ck.scene_hash = renderContentHash(hostSceneFlat().desc, sc.camera);
 	ck.max_ray_bounces = sc.camera.max_ray_bounces;
 	ck.texture_enabled = sc.camera.texture_enabled ? 1 : 0;
 	ck.rgba.resize((size_t)ck.width * ck.height * 4);
@@ -285,7 +285,7 @@ extern "C" int pth_checkpoint_load(const char* path, int* samples_done) {
 		return PTX_E_INVALID;
 	}
 	if (ck.seed != kernelSeed()) { g_err = "pth_checkpoint_load: checkpoint was rendered with another seed"; return PTX_E_INVALID; }
-	const std::string why = checkpointMismatch(ck, sceneContentHash(hostSceneFlat().desc), sc.camera.max_ray_bounces, sc.camera.texture_enabled ? 1 : 0);
+	const std::string why = checkpointMismatch(ck, renderContentHash(hostSceneFlat().desc, sc.camera), sc.camera.max_ray_bounces, sc.camera.texture_enabled ? 1 : 0);
 	if (!why.empty()) { g_err = "pth_checkpoint_load: checkpoint does not continue this render: " + why; return PTX_E_INVALID; }
 	int rc = ptx_accum_upload(ctx, ck.rgba.data());
 	if (rc != PTX_OK) { g_err = ptx_last_error(); return rc; }

@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
 	auto save_checkpoint = [&](int done) {
 		AccumCheckpoint ck;
 		ck.width = W; ck.height = H; ck.samples_done = done; ck.seed = seed;
-		ck.scene_hash = sceneContentHash(hostSceneFlat().desc);
+		ck.scene_hash = renderContentHash(hostSceneFlat().desc, scene.camera);
 		ck.max_ray_bounces = scene.camera.max_ray_bounces;
 		ck.texture_enabled = scene.camera.texture_enabled ? 1 : 0;
 		ck.rgba.resize((size_t)W * H * 4);
@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
 			        (unsigned long long)ck.seed, W, H, seed);
 			return 1;
 		}
-		const std::string why = checkpointMismatch(ck, sceneContentHash(hostSceneFlat().desc), scene.camera.max_ray_bounces,
+		const std::string why = checkpointMismatch(ck, renderContentHash(hostSceneFlat().desc, scene.camera), scene.camera.max_ray_bounces,
 		                                           scene.camera.texture_enabled ? 1 : 0);
 		if (!why.empty()) { fprintf(stderr, "checkpoint %s does not continue this render: %s\n", resume_path.c_str(), why.c_str()); return 1; }
 		if (ck.samples_done > spp) {

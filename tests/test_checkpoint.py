@@ -95,4 +95,12 @@ def test_checkpoint_of_another_scene_bounce_limit_or_texture_switch_is_refused(p
     pt.load_scene("geoms", width=64, height=48)
     assert H.pth_kernel_init() == 0
     assert H.pth_checkpoint_load(path, C.byref(done)) != 0 and b"different scene" in H.pth_last_error()
+    # the same scene seen by a moved camera is another image: refused, and accepted again once the camera is back
+    pt.load_scene("teapot", width=64, height=48)
+    assert H.pth_kernel_init() == 0
+    assert H.pth_checkpoint_load(path, C.byref(done)) == 0
+    assert H.pth_camera_control(b"h_ang", 10.0) == 0
+    assert H.pth_checkpoint_load(path, C.byref(done)) != 0 and b"camera" in H.pth_last_error()
+    assert H.pth_camera_control(b"reset", 0.0) == 0
+    assert H.pth_checkpoint_load(path, C.byref(done)) == 0
     H.pth_set_seed(0)
