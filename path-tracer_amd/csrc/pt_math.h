@@ -61,8 +61,20 @@ PT_DEV float pt_rcp_det(float a) {
 	if (__ballot(__builtin_fabsf(a) > PT_RCP_HI) != 0ull) return 1.0f / a;
 	return pt_rcp_newton(a);
 }
+// 1.0f / a for any a: the five-instruction form where it is proven equal (the wave takes the division if one of its lanes
+// holds a value outside the checked range, a zero or a NaN: both paths give the same bits inside it, so which one a wave
+// takes never shows in a result). Lengths and ray directions are inside the range in practice.
+PT_DEV bool pt_rcp_in_range(float a) { const float m = __builtin_fabsf(a); return m >= PT_RCP_LO && m <= PT_RCP_HI; }
+PT_DEV float pt_rcp(float a) {
+	if (__ballot(!pt_rcp_in_range(a)) != 0ull) return 1.0f / a;
+	return pt_rcp_newton(a);
+}
+PT_DEV f3 pt_rcp3(f3 a) {
+	if (__ballot(!(pt_rcp_in_range(a.x) && pt_rcp_in_range(a.y) && pt_rcp_in_range(a.z))) != 0ull) return mk3(1.0f / a.x, 1.0f / a.y, 1.0f / a.z);
+	return mk3(pt_rcp_newton(a.x), pt_rcp_newton(a.y), pt_rcp_newton(a.z));
+}
 PT_DEV f3 normalize3(f3 v) {
-	float invLen = 1.0f / pt_sqrt(dot3(v, v));
+	float invLen = pt_rcp(pt_sqrt(dot3(v, v)));   // == 1.0f / sqrt(dot(v, v)) bit for bit
 	return v * invLen;
 }
 PT_DEV f3 reflect3(f3 i, f3 n) { return i - (2.0f * n) * dot3(n, i); }

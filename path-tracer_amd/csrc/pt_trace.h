@@ -24,7 +24,7 @@ struct Ray {
 PT_DEV void init_ray(Ray& r, f3 orig, f3 dir) {
 	r.d = dir;
 	r.o = orig;
-	r.inv = mk3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+	r.inv = pt_rcp3(dir);   // == 1.0f / dir.x, ... bit for bit (pt_math.h)
 	r.sx = r.inv.x < 0.0f;
 	r.sy = r.inv.y < 0.0f;
 	r.sz = r.inv.z < 0.0f;

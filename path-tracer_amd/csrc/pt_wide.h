@@ -212,7 +212,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 					cur_obj_r = __float_as_int(wp.s2[path].w);
 					o = mk3(a0.x, a0.y, a0.z);
 					d = mk3(a1.x, a1.y, a1.z);
-					inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+					inv = pt_rcp3(d);
 					cur_d = a0.w;
 					tmin = __builtin_huge_valf();
 					curr = root;
@@ -243,26 +243,32 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 			               w3 = __float_as_uint(f2.y), w4 = __float_as_uint(f2.z), w5 = __float_as_uint(f2.w);
 			const int r0 = __float_as_int(f3.x), r1 = __float_as_int(f3.y), r2 = __float_as_int(f3.z), r3 = __float_as_int(f3.w);
 			gref0 = r0; gref1 = r1; gref2 = r2; gref3 = r3;
+			// The six code words are axis-major (ptx_hip.hip, quantise_boxes4): the ray's NEAR face of every child on an axis is
+			// the lo word if it travels upwards there and the hi word otherwise, so the near / far choice is one swap of two
+			// words per axis and the per-child work is six conversions, six fma, one max3, one min3. (min / max pairs per
+			// child and axis cost 24 instructions of the half-rate kind; tools/micro/valu_rate.hip.) fma is monotonic in
+			// the code, so near <= far as before; a NaN (0 * inf: the ray runs in a face's plane) drops out of max3 / min3
+			// as it did out of min / max: that axis does not constrain.
+			const bool ngx = sx < 0.0f, ngy = sy < 0.0f, ngz = sz < 0.0f;
+			const uint32_t nx = ngx ? w1 : w0, fx = ngx ? w0 : w1, ny = ngy ? w3 : w2, fy = ngy ? w2 : w3, nz = ngz ? w5 : w4, fz = ngz ? w4 : w5;
 #define WFW_QB(W, K) ((float)(((W) >> (8 * (K))) & 0xffu))
-			// slab test on min / max (a NaN from 0 * inf drops out: that axis does not constrain); entry distance out
-			auto hit = [&](float lx, float ly, float lz, float hx, float hy, float hz, float& tn) {
-				const float tax = __builtin_fmaf(lx, sx, ax), tbx = __builtin_fmaf(hx, sx, ax);
-				const float tay = __builtin_fmaf(ly, sy, ay), tby = __builtin_fmaf(hy, sy, ay);
-				const float taz = __builtin_fmaf(lz, sz, az), tbz = __builtin_fmaf(hz, sz, az);
-				tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tax, tbx), __builtin_fminf(tay, tby)), __builtin_fminf(taz, tbz));
-				const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tax, tbx), __builtin_fmaxf(tay, tby)), __builtin_fmaxf(taz, tbz));
-				return !(tn > tf) && !(tf < 0.0f) && !(tn > tmin);
+			// entry distance out (clamped at the origin); hit = the slabs overlap in front of the origin, not beyond the bound
+			auto hit = [&](float qnx, float qny, float qnz, float qfx, float qfy, float qfz, float& tn) {
+				const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(qnx, sx, ax), __builtin_fmaf(qny, sy, ay)), __builtin_fmaf(qnz, sz, az));
+				const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaf(qfx, sx, ax), __builtin_fmaf(qfy, sy, ay)), __builtin_fmaf(qfz, sz, az));
+				tn = __builtin_fmaxf(tnear, 0.0f);
+				return !(tn > tfar) && !(tn > tmin);
 			};
 			float n0, n1, n2, n3;
-			const bool h0 = hit(WFW_QB(w0, 0), WFW_QB(w0, 1), WFW_QB(w0, 2), WFW_QB(w0, 3), WFW_QB(w1, 0), WFW_QB(w1, 1), n0) & (r0 != -1);
-			const bool h1 = hit(WFW_QB(w1, 2), WFW_QB(w1, 3), WFW_QB(w2, 0), WFW_QB(w2, 1), WFW_QB(w2, 2), WFW_QB(w2, 3), n1) & (r1 != -1);
-			const bool h2 = hit(WFW_QB(w3, 0), WFW_QB(w3, 1), WFW_QB(w3, 2), WFW_QB(w3, 3), WFW_QB(w4, 0), WFW_QB(w4, 1), n2) & (r2 != -1);
-			const bool h3 = hit(WFW_QB(w4, 2), WFW_QB(w4, 3), WFW_QB(w5, 0), WFW_QB(w5, 1), WFW_QB(w5, 2), WFW_QB(w5, 3), n3) & (r3 != -1);
+			const bool h0 = hit(WFW_QB(nx, 0), WFW_QB(ny, 0), WFW_QB(nz, 0), WFW_QB(fx, 0), WFW_QB(fy, 0), WFW_QB(fz, 0), n0) & (r0 != -1);
+			const bool h1 = hit(WFW_QB(nx, 1), WFW_QB(ny, 1), WFW_QB(nz, 1), WFW_QB(fx, 1), WFW_QB(fy, 1), WFW_QB(fz, 1), n1) & (r1 != -1);
+			const bool h2 = hit(WFW_QB(nx, 2), WFW_QB(ny, 2), WFW_QB(nz, 2), WFW_QB(fx, 2), WFW_QB(fy, 2), WFW_QB(fz, 2), n2) & (r2 != -1);
+			const bool h3 = hit(WFW_QB(nx, 3), WFW_QB(ny, 3), WFW_QB(nz, 3), WFW_QB(fx, 3), WFW_QB(fy, 3), WFW_QB(fz, 3), n3) & (r3 != -1);
 #undef WFW_QB
 			gh = ((h0 & (r0 < 0)) ? 1u : 0u) | ((h1 & (r1 < 0)) ? 2u : 0u) | ((h2 & (r2 < 0)) ? 4u : 0u) | ((h3 & (r3 < 0)) ? 8u : 0u);
 			// inner children, nearest first: sort (entry distance with the slot in its two lowest bits)
 			auto skey = [](bool on, float tn, uint32_t slot) {
-				return on ? ((__float_as_uint(__builtin_fmaxf(tn, 0.0f)) & ~3u) | slot) : 0xffffffffu;
+				return on ? ((__float_as_uint(tn) & ~3u) | slot) : 0xffffffffu;
 			};
 			uint32_t k0 = skey(h0 & (r0 >= 0), n0, 0u), k1 = skey(h1 & (r1 >= 0), n1, 1u), k2 = skey(h2 & (r2 >= 0), n2, 2u), k3 = skey(h3 & (r3 >= 0), n3, 3u);
 #define WFW_CX(A, B) { const uint32_t lo_ = A < B ? A : B, hi_ = A < B ? B : A; A = lo_; B = hi_; }

@@ -306,7 +306,10 @@ static void free_scene_allocs(PtxScene* s) {
 // Four boxes in 48 bytes (pt_scene.h, grp_qbox / wide nodes): the union U of the used boxes as origin and
 // step = extent / 255 per axis, then per box six bytes (lo.xyz rounded down, hi.xyz rounded up, in steps from U's
 // origin). The decoded box always contains the given one; an unused slot is (255, 255, 255, 0, 0, 0): never touched.
-static void quantise_boxes4(const float lo[4][3], const float hi[4][3], const bool used[4], float4 out[3]) {
+// Byte order: box-major (box g = bytes 6g .. 6g+5: lo.xyz, hi.xyz; the exact kernel's grp_qbox) or, for the wide nodes,
+// AXIS-major (word 2k = the four lo codes of axis k, word 2k+1 the four hi codes, box g in byte g): a ray then picks its
+// near and far faces per axis by swapping two words on the sign of its direction, once per node instead of once per box.
+static void quantise_boxes4(const float lo[4][3], const float hi[4][3], const bool used[4], float4 out[3], bool axis_major = false) {
 	double ulo[3] = {1e300, 1e300, 1e300}, uhi[3] = {-1e300, -1e300, -1e300};
 	for (int g = 0; g < 4; ++g) {
 		if (!used[g]) continue;
@@ -339,6 +342,11 @@ static void quantise_boxes4(const float lo[4][3], const float hi[4][3], const bo
 				q[6 * g + 3 + k] = (unsigned char)qh;
 			}
 		}
+	}
+	if (axis_major) {
+		unsigned char t[24];
+		for (int g = 0; g < 4; ++g) for (int k = 0; k < 3; ++k) { t[8 * k + g] = q[6 * g + k]; t[8 * k + 4 + g] = q[6 * g + 3 + k]; }
+		memcpy(q, t, 24);
 	}
 	uint32_t w[6];
 	memcpy(w, q, 24);
@@ -606,7 +614,7 @@ struct WideBuilder {
 			else { ref[i] = first + (int)i; children(list[i], ch); emit(first + (int)i, ch, below); }
 		}
 		float4 q[3];
-		quantise_boxes4(lo, hi, used, q);
+		quantise_boxes4(lo, hi, used, q, true);
 		out[(size_t)idx * 4 + 0] = q[0]; out[(size_t)idx * 4 + 1] = q[1]; out[(size_t)idx * 4 + 2] = q[2];
 		out[(size_t)idx * 4 + 3] = make_float4(as_float(ref[0]), as_float(ref[1]), as_float(ref[2]), as_float(ref[3]));
 	}
