@@ -347,6 +347,10 @@ def main():
             "ta_busy_frac": round(ta, 4),
             "valu_issue_frac_2cyc_per_inst": round(valu2, 4),
             "valu_issue_frac_4cyc_per_inst": round(d.get("valu_issue_frac_4cyc", 0.0) * scale, 4),
+            # tools/micro/valu_rate.hip: only f32 add / mul / fma, mov, integer add and and / or / xor issue at the 2-cycle rate; compares,
+            # selects, min / max, conversions, lane moves and packed f32 take ~1.65x as long. Estimate from the class counters:
+            "valu_issue_frac_weighted_est": round(d.get("valu_issue_frac_weighted_est", 0.0) * scale, 4) or None,
+            "valu_mix": d.get("valu_mix"),
             "active_lanes_per_valu_inst": round(d.get("active_lanes_per_valu_inst", 0.0), 2),
             "valu_useful_frac": round(valu2 * d.get("active_lanes_per_valu_inst", 0.0) / 64.0, 4),
             "l1_to_l2_read": {"achieved": round(l2_gbs, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(l2_gbs / L2_PEAK_GBS, 4)},

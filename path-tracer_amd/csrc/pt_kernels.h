@@ -126,6 +126,7 @@ __global__ __launch_bounds__(PT_BLOCK) void render_kernel(DevScene sc, DevCamera
 					}
 					const u4 rnd = philox4x32_10(pixel, (uint32_t)s, (uint32_t)bounce, 0u, k0, k1);
 					done = shade_segment(sc, cam, hi, ray, mask, rnd, out);
+					if (!done) init_ray(ray, ray.o, ray.d);   // the BSDF set origin and direction (pt_shade.h)
 					bounce++;
 				}
 			}

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 			Rad3* rad_slot = wp.rad + (size_t)sl * (size_t)wp.npix + pixel;
 
 			Ray ray;
-			init_ray(ray, ro, rd);
+			set_ray(ray, ro, rd);   // shading reads origin and direction only; the inverse is formed once, for the rays that go on
+			ray.inv = mk3(0.0f); ray.sx = ray.sy = ray.sz = false;
 			int shade_type = -1;
 			if (alive) {
 				if (bs < 0) {
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 						n_paths++;
 						alive = false;
 					} else {
-						init_ray(ray, ray.o, ray.d);   // the BSDF set origin and direction: inverse direction anew
+						init_ray(ray, ray.o, ray.d);   // the BSDF set origin and direction (pt_shade.h): the inverse for the root-box tests below
 					}
 				}
 			}

@@ -1,6 +1,8 @@
 // BSDF sampling and per-segment shading (reference: src/surfaces.cuh:14-137,
 // src/radiance.cuh:15-87), one path per lane. Uniforms come from one Philox call per
 // bounce (pt_math.h) and are consumed in the order the reference draws them.
+// The BSDFs leave the new ray's ORIGIN and DIRECTION in `ray` (set_ray, pt_trace.h): the caller that intersects next
+// computes the inverse direction (init_ray(ray, ray.o, ray.d)), once.
 #pragma once
 #include "pt_trace.h"
 
@@ -36,7 +38,7 @@ PT_DEV f3 rand_cone_dir(f3 axis, float ang_max_dev, UniformStream& rs) {
 // reference: src/surfaces.cuh:37-44 Diffuse_BRDF
 PT_DEV void diffuse_brdf(Ray& ray, f3 n, f3 ip, UniformStream& rs) {
 	f3 dir = rand_cone_dir(n, PT_PI_D2, rs);
-	init_ray(ray, ip + n * 0.00005f, dir);
+	set_ray(ray, ip + n * 0.00005f, dir);
 }
 
 // reference: src/surfaces.cuh:48-70 Specular_Diffuse_BRDF
@@ -50,7 +52,7 @@ PT_DEV void specular_diffuse_brdf(Ray& ray, float refl_factor, float sharpness, 
 		const float scatt_ang = PT_PI_D2 - pt_acos01(fabsf(dot3(ray.d, n)));
 		const float ang = (scatt_ang < max_cone_ang) ? scatt_ang : max_cone_ang; // fmin(max_cone, scatt)
 		f3 dir = rand_cone_dir(reflect3(ray.d, n), ang, rs);
-		init_ray(ray, new_orig, dir);
+		set_ray(ray, new_orig, dir);
 	}
 }
 
@@ -64,7 +66,7 @@ PT_DEV void refractive_brdf(Ray& ray, float n_obj, float refl_factor, f3& mask, 
 	float cos2refr = 1.0f - nn * nn * (1.0f - cos_ray * cos_ray);
 	if (cos2refr < 0.0f) {
 		// total internal reflection
-		init_ray(ray, ip + n_or * REFL_BIAS, reflect3(ray.d, n_or));
+		set_ray(ray, ip + n_or * REFL_BIAS, reflect3(ray.d, n_or));
 	} else {
 		float cosrefr = pt_sqrt(cos2refr);
 		f3 trans = normalize3(ray.d * nn - n * ((outside ? 1.0f : -1.0f) * (cos_ray * nn + cosrefr)));
@@ -76,10 +78,10 @@ PT_DEV void refractive_brdf(Ray& ray, float n_obj, float refl_factor, f3& mask, 
 		float energy = refl_factor + (1.0f - refl_factor - refl_factor) * reflectance;
 		if (rs.draw() < refl_factor) {
 			mask = mask * (reflectance / energy);
-			init_ray(ray, ip + n_or * REFL_BIAS, reflect3(ray.d, n));
+			set_ray(ray, ip + n_or * REFL_BIAS, reflect3(ray.d, n));
 		} else {
 			mask = mask * ((1.0f - reflectance) / (1.0f - energy));
-			init_ray(ray, ip - n_or * REFL_BIAS_LOW, trans);
+			set_ray(ray, ip - n_or * REFL_BIAS_LOW, trans);
 		}
 	}
 }

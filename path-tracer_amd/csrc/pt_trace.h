@@ -30,6 +30,14 @@ PT_DEV void init_ray(Ray& r, f3 orig, f3 dir) {
 	r.sz = r.inv.z < 0.0f;
 }
 
+// Origin and direction only: for code that shades (the BSDFs, src/surfaces.cuh) and hands the ray on. The inverse and its
+// signs are then NOT valid; whoever intersects next calls init_ray(r, r.o, r.d) - once, where the reference's BSDFs each
+// end in init_ray and the wavefront kernels used to add two more (3 exact reciprocals each).
+PT_DEV void set_ray(Ray& r, f3 orig, f3 dir) {
+	r.d = dir;
+	r.o = orig;
+}
+
 struct TraceCounters {
 	uint32_t n_inner, n_box, n_tri, n_leaf, n_sphere, leaf_hash;
 };

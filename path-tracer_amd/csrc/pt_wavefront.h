@@ -343,7 +343,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 			if (bounce == 0) {
 				f3 mid, centre;
 				pixel_midpoint(cam, x, y, mid, centre);
-				init_ray(ray, cam_pos, jittered_dir(cam, mid, pixel, sample, wp.k0, wp.k1));
+				set_ray(ray, cam_pos, jittered_dir(cam, mid, pixel, sample, wp.k0, wp.k1));   // phase 2 forms the inverse (from LDS)
 				if (wp.is_last) { // max_ray_bounces == 0: the bounce loop never runs
 					*rad_slot = Rad3{0.0f, 0.0f, 0.0f};
 					n_paths++;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 				}
 			} else {
 				// ---- resolve the closest hit of the previous segment and shade it ------------------
-				init_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
+				set_ray(ray, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z));
 				mask = mk3(a2.x, a2.y, a2.z);
 				const int best_obj = __float_as_int(a2.w);
 				f3 out = mk3(0.0f);
