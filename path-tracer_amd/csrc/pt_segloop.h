@@ -53,6 +53,13 @@
 #ifndef WSL_OCC
 #define WSL_OCC 4
 #endif
+// The triangles of the single-leaf meshes (sky cube, floor, ...) are copied into LDS when all their runs fit: the pair
+// loop of leaf_only_mesh_pairs fetches them per lane (6 x 16 B per touched pair, each a line of its own for the L1) in a
+// chain of dependent loads. 16 triangles = 768 B: 5.60 -> 5.50 ms per launch; with 32 (1.5 KB) the workgroup's LDS passes
+// what five workgroups per CU can have and the kernel runs at 6.24 ms. Scenes with more fall back to tri_geom.
+#ifndef WSL_LDS_TRIS
+#define WSL_LDS_TRIS 16
+#endif
 template <int FLAGS, int LDSTAB>
 __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevScene sc, DevCamera cam, WfParams wp) {
 	const int tid = threadIdx.x, lane = tid & 63;
@@ -87,6 +94,31 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 #define WSL_CLOCK() (((FLAGS & PT_F_STATS) && (threadIdx.x & 63) == 0) ? (unsigned long long)__builtin_amdgcn_s_memtime() : 0ull)
 	uint64_t sc0 = 0, sc1 = 0, sc2 = 0, sc3 = 0;
 
+	// single-leaf meshes: runs (rounded up to pairs: the slot behind an odd run is tri_geom's zero record) copied in object order
+	__shared__ float4 sh_tri[3 * WSL_LDS_TRIS];
+	bool tris_in_lds = WSL_LDS_TRIS > 0;
+	{
+		int total = 0;
+		for (int oi = 0; oi < sc.num_objects; ++oi) {
+			const DevObject& ob = sc.objects[oi];
+			if (ob.type != 0 && ob.root_node >= 0 && ob.big_slot < 0)
+				total += (__builtin_amdgcn_readfirstlane(__float_as_int(sc.nodes[4 * ob.root_node + 3].w)) + 1) & ~1;
+		}
+		tris_in_lds = tris_in_lds && total <= WSL_LDS_TRIS;
+		if (tris_in_lds) {
+			int off = 0;
+			for (int oi = 0; oi < sc.num_objects; ++oi) {
+				const DevObject& ob = sc.objects[oi];
+				if (ob.type != 0 && ob.root_node >= 0 && ob.big_slot < 0) {
+					const float4 q3 = sc.nodes[4 * ob.root_node + 3];
+					const int first = __builtin_amdgcn_readfirstlane(__float_as_int(q3.z));
+					const int n2 = (__builtin_amdgcn_readfirstlane(__float_as_int(q3.w)) + 1) & ~1;
+					for (int i = tid; i < 3 * n2; i += PT_BLOCK) sh_tri[3 * off + i] = sc.tri_geom[3 * first + i];
+					off += n2;
+				}
+			}
+		}
+	}
 	__shared__ int sh_pool_cur;
 	if (tid == 0) { sh_pool = 0; sh_live = 0; }
 	bool exhausted = n_in <= 0;   // block-uniform: the input has no entry left to claim
@@ -304,6 +336,7 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 			int best_obj = -1, best_tri = -1;
 			if (alive) n_rays++;
 			const int nobj = sc.num_objects;
+			int lds_off = 0;   // where the current single-leaf mesh's run starts in sh_tri (wave-uniform)
 			for (int oi = 0; oi < nobj; ++oi) {
 				const DevObject& ob = sc.objects[oi];
 				if (ob.type == 0) {
@@ -326,13 +359,19 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 					if (enter) {
 						float tmin = __builtin_huge_valf(), bu = 0.0f, bv = 0.0f;
 						int tri = -1;
-						bool hit = WF_CHEAP_PAIRS ? leaf_only_mesh_pairs<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt) : leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
+						const int run_off = lds_off;
+						auto fetch = [&](int first, int rel, float4& g0, float4& g1, float4& g2) {
+							if (tris_in_lds) { const int q = 3 * (run_off + rel); g0 = sh_tri[q]; g1 = sh_tri[q + 1]; g2 = sh_tri[q + 2]; }
+							else { const int q = 3 * (first + rel); g0 = sc.tri_geom[q]; g1 = sc.tri_geom[q + 1]; g2 = sc.tri_geom[q + 2]; }
+						};
+						bool hit = WF_CHEAP_PAIRS ? leaf_only_mesh_pairs<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt, fetch) : leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
 						if (hit && tri >= 0) {
 							const f3 p = ray.o + tmin * ray.d;
 							const float d = length3(p - ray.o);
 							if (d < best_dist) { best_dist = d; best_t = tmin; best_obj = oi; best_tri = tri; b_u = bu; b_v = bv; }
 						}
 					}
+					if (tris_in_lds) lds_off += (__builtin_amdgcn_readfirstlane(__float_as_int(sc.nodes[4 * ob.root_node + 3].w)) + 1) & ~1;
 				}
 			}
 			const bool leaves = alive && flags != 0u;

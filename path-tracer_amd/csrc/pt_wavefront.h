@@ -209,9 +209,17 @@ PT_DEV bool leaf_only_mesh(const DevScene& sc, const DevObject& ob, const Ray& r
 // (its own loads from tri_geom), in run order with strict '<' - what the serial loop above keeps, because a pair
 // whose padded box the ray misses holds no hit (the argument of the group boxes). A ray inside the
 // sky cube tests one face instead of twelve triangles; the loop below runs once for most waves.
-template <int FLAGS>
+// `fetch(first, rel, g0, g1, g2)`: the three words of triangle first + rel of tri_geom - from global memory, or from a
+// copy of the single-leaf meshes' runs in LDS (pt_segloop.h): the loop below is a chain of dependent loads.
+struct GlobalTriFetch {
+	const float4* tri_geom;
+	PT_DEV void operator()(int first, int rel, float4& g0, float4& g1, float4& g2) const {
+		g0 = tri_geom[3 * (first + rel) + 0]; g1 = tri_geom[3 * (first + rel) + 1]; g2 = tri_geom[3 * (first + rel) + 2];
+	}
+};
+template <int FLAGS, class Fetch>
 PT_DEV bool leaf_only_mesh_pairs(const DevScene& sc, const DevObject& ob, const Ray& ray, float& tmin, int& best_tri,
-                                 float& bu, float& bv, TraceCounters& cnt) {
+                                 float& bu, float& bv, TraceCounters& cnt, const Fetch& fetch) {
 	const float4 q3 = sc.nodes[4 * ob.root_node + 3];
 	const float4 q0 = sc.nodes[4 * ob.root_node + 0];
 	const int first = __builtin_amdgcn_readfirstlane(__float_as_int(q3.z));
@@ -242,7 +250,8 @@ PT_DEV bool leaf_only_mesh_pairs(const DevScene& sc, const DevObject& ob, const 
 				const int t0 = first + 2 * (base + j);
 #pragma unroll
 				for (int h = 0; h < 2; ++h) {   // the slot behind an odd run's last triangle is a zero record: never hit
-					const float4 g0 = sc.tri_geom[3 * (t0 + h) + 0], g1 = sc.tri_geom[3 * (t0 + h) + 1], g2 = sc.tri_geom[3 * (t0 + h) + 2];
+					float4 g0, g1, g2;
+					fetch(first, 2 * (base + j) + h, g0, g1, g2);
 					float t, u, v;
 					if (tri_test_flat(ray, mk3(g0.x, g0.y, g0.z), mk3(g0.w, g1.x, g1.y), mk3(g1.z, g1.w, g2.x), t, u, v)) {
 						intersects = true;
@@ -253,6 +262,11 @@ PT_DEV bool leaf_only_mesh_pairs(const DevScene& sc, const DevObject& ob, const 
 		}
 	}
 	return intersects;
+}
+template <int FLAGS>
+PT_DEV bool leaf_only_mesh_pairs(const DevScene& sc, const DevObject& ob, const Ray& ray, float& tmin, int& best_tri,
+                                 float& bu, float& bv, TraceCounters& cnt) {
+	return leaf_only_mesh_pairs<FLAGS>(sc, ob, ray, tmin, best_tri, bu, bv, cnt, GlobalTriFetch{sc.tri_geom});
 }
 
 #ifndef WF_CHEAP_PAIRS
