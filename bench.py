@@ -423,8 +423,9 @@ def main():
                 "the vector-memory front end (texture-addresser busy) against VALU issue at 2 cycles per wave64 instruction "
                 "(MI355X_MICROARCH.md). Not HBM: the trees are cache-resident and the path state streams at a third of the HBM "
                 "rate (pmc.hbm_side; traffic = measured L2-miss side per launch; `algorithmic` = unavoidable HBM bytes over the launch time "
-                "against 8 TB/s). Sensitivity of the wide traversal: 24 extra VALU instructions per node visit cost 1 %, one extra "
-                "L1-hitting load per visit 3 % (DESIGN.md 3.4)",
+                "against 8 TB/s). pmc.valu_issue_frac_weighted_est prices the instruction classes at their measured issue cost "
+                "(tools/micro/valu_rate.hip: compares, selects, min / max, conversions take 1.65x an fma): by it the vector unit is "
+                "the close second limit of both kernels (DESIGN.md 3.4)",
     })
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------
