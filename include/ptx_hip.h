@@ -256,7 +256,7 @@ int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches,
  *                     million of the mesh diagonal, on top of 5e-5); read by the NEXT ptx_scene_upload
  *   "seg_lds_tables"  material / texture-descriptor tables of the segment kernel in LDS: 0 never, 1 (default) for the per-bounce kernel only
  *                     (the bounce-loop kernel would lose its fifth wave per SIMD to them), 2 for both
- *   "trav_blocks"     persistent workgroups per CU;  "wf_batch"  samples per wavefront pass (1..256, default 128)
+ *   "trav_blocks"     persistent workgroups per CU (the wide kernel launches at most six: what is resident);  "wf_batch"  samples per wavefront pass (1..256, default 128)
  *   "megakernel"      1 = one-lane-per-pixel kernel instead of the wavefront pipeline
  * WHAT CAN CHANGE A RESULT: nothing but "trav_variant" 0 / 14 together with "wide_margin_ppm", and only on rays at grazing
  * incidence where the reference's triangle test accepts a hit out of rounding noise (|det| ~ 1e-7 |e1||e2|) on a triangle

@@ -40,7 +40,7 @@
 //     merges the hits into the owners' keys with LDS atomic minima; the owners then lower their culling bound.
 //   * once TURN_MIN lanes have finished, the remaining units are tested, finished lanes commit (closest object by
 //     distance, as the reference's loop over the objects: src/intersect.cuh:328-346) and idle lanes take new rays.
-// Default configuration <6 waves/SIMD, chunks of 128, turn at 16 waiting lanes, drain at 32 units>: 80 registers.
+// Default configuration <6 waves/SIMD, chunks of 256, turn at 24 waiting lanes, drain at 16 units>: 80 registers.
 #pragma once
 #include "pt_wavefront.h"
 
@@ -52,7 +52,7 @@
 
 template <int FLAGS, int OCC, int CHUNK, int TURN_MIN, int DRAIN_MIN>
 __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScene sc, WfParams wp, int obj_index, int slot_index, int scap, float cull_rel, float cull_abs) {
-	static_assert(CHUNK >= 1 && CHUNK <= 128, "a chunk's queue entries are held two per lane");
+	static_assert(CHUNK >= 64, "a refill takes up to 64 entries of the chunk at a time");
 	static_assert(DRAIN_MIN >= 16 && DRAIN_MIN <= 64 && 63 + 256 < WFW_UNIT_CAP, "the unit list must hold one more iteration's appends");
 	extern __shared__ int lds_stack[];
 	const int tid = threadIdx.x, lane = tid & 63;

@@ -113,11 +113,14 @@ static int env_int(const char* name, int dflt) {
 #ifndef WF_CHUNK
 #define WF_CHUNK 128
 #endif
+#ifndef WFW_CHUNK
+#define WFW_CHUNK 256   // the wide kernel's own chunk: 128 / 192 / 256 / 512 / 1024 -> 7.02 / 6.88 / 6.84 / 6.97 / 7.28 ms (a claim is a returning atomic in a turn)
+#endif
 #ifndef WFW_TURN_MIN
-#define WFW_TURN_MIN 16
+#define WFW_TURN_MIN 24   // re-swept after the node visit lost a fifth of its instructions: 12 / 16 / 20 / 24 / 32 -> 7.34 / 7.16 / 7.10 / 7.06 / 7.11 ms
 #endif
 #ifndef WFW_DRAIN_MIN
-#define WFW_DRAIN_MIN 32
+#define WFW_DRAIN_MIN 16  // with TURN_MIN 24: 16 / 24 / 32 -> 7.03 / 7.04 / 7.06 ms (48: 7.21)
 #endif
 #ifndef WF_ATHRESH
 #define WF_ATHRESH 28
@@ -1188,7 +1191,10 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	const int scap = scene->dev.wide_stack < ctx->wide_scap ? scene->dev.wide_stack : ctx->wide_scap;
 	const size_t wide_lds = (size_t)scap * PT_BLOCK * WFW_STACK_ENTRY_BYTES + WFW_BYTES;
 	// <stats, waves/SIMD for the register allocator, queue chunk, lanes that must wait before a turn, units that must gather before a drain>
-#define WIDE(F) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, 6, WF_CHUNK, WFW_TURN_MIN, WFW_DRAIN_MIN>), dim3((unsigned)tb), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap, 1.0f + 1e-6f * (float)ctx->wide_margin_ppm, 1e-6f * (float)ctx->wide_margin_ppm)
+	// the wide kernel's grid: no more workgroups than are resident at once (six per CU: registers and LDS), so that none starts into a
+	// drained queue behind another (16 / 12 / 6 per CU: 6.85 / 6.83 / 6.78 ms); trav_blocks below six still lowers it
+	const size_t tbw = (size_t)cus * (size_t)(ctx->trav_blocks_per_cu < 6 ? ctx->trav_blocks_per_cu : 6);
+#define WIDE(F) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, 6, WFW_CHUNK, WFW_TURN_MIN, WFW_DRAIN_MIN>), dim3((unsigned)tbw), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap, 1.0f + 1e-6f * (float)ctx->wide_margin_ppm, 1e-6f * (float)ctx->wide_margin_ppm)
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
 	// the exact kernel in the best leaf mode the tree's stack leaves LDS for (or the one a test asks for)
