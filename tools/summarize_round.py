@@ -82,18 +82,23 @@ for k, c in sums.items():
             d["valu_issue_frac_2cyc"] = c["SQ_INSTS_VALU"] * 2.0 / (SIMDS * cyc)
             d["valu_issue_frac_4cyc"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (SIMDS * cyc)
     if g and c.get("SQ_INSTS_VALU") and "SQ_INSTS_VALU_FMA_F32" in c:
-        # tools/micro/valu_rate.hip, 6 waves per SIMD: f32 add / mul / fma (and mov, integer add, and / or / xor) issue at 1.10 ns, nearly
-        # everything else (min / max, compares, selects, conversions, shifts with add, bit-field, lane moves, packed f32) at 1.82 ns,
-        # transcendentals at 3.45 ns. The class counters only name part of the stream: add + mul + fma are priced fast, conversions and
-        # the UNNAMED rest (mov, compare, select, min / max, ...) slow, integer work half and half. An estimate, beside the two bounds.
+        # tools/micro/valu_rate.hip (2 ... 6 waves per SIMD, shader-clock ticks and wall clock agree): f32 add / mul / fma (and mov,
+        # integer add, and / or / xor, right shifts) issue every 2.33 cycles, nearly everything else (min / max, compares, selects,
+        # conversions, left shifts, bit-field, integer multiply-add, lane moves, packed f32) every 3.85, transcendentals every 7.3.
+        # The class counters name only part of the stream: add + mul + fma are priced fast, transcendentals as such, integer work
+        # half and half, and the UNNAMED rest (mov, compare, select, min / max, conversions ...) slow. An estimate built from measured
+        # counts and measured costs; the split of the unnamed rest is the assumption (all of it fast would give the lower figure).
+        CY_FAST, CY_SLOW, CY_TRANS = 2.33, 3.85, 7.3
         n_all = c["SQ_INSTS_VALU"]
         fast = c.get("SQ_INSTS_VALU_ADD_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c["SQ_INSTS_VALU_FMA_F32"]
         trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0)
         i32 = c.get("SQ_INSTS_VALU_INT32", 0)
         rest = max(0.0, n_all - fast - trans - i32)
-        rel = (fast * 1.0 + trans * 3.45 / 1.10 + i32 * 0.5 * (1.0 + 1.82 / 1.10) + rest * 1.82 / 1.10) / n_all
+        cyc_est = fast * CY_FAST + trans * CY_TRANS + i32 * 0.5 * (CY_FAST + CY_SLOW) + rest * CY_SLOW
         d["valu_mix"] = {"f32_add_mul_fma": fast / n_all, "transcendental": trans / n_all, "int32": i32 / n_all, "cvt": c.get("SQ_INSTS_VALU_CVT", 0) / n_all}
-        d["valu_issue_frac_weighted_est"] = n_all * 2.0 * rel / (SIMDS * g / 8.0)
+        d["valu_issue_cycles_weighted_est"] = cyc_est
+        d["valu_issue_frac_weighted_est"] = cyc_est / (SIMDS * g / 8.0)
+        d["valu_issue_frac_all_fast"] = n_all * CY_FAST / (SIMDS * g / 8.0)
     if c.get("SQ_ACTIVE_INST_VALU"):
         d["active_lanes_per_valu_inst"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
     if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c:
