@@ -329,11 +329,20 @@ def main():
         scale = prof_ms / launch_ms if launch_ms > 0 else 1.0
         ta = d["ta_busy_frac"] * scale
         valu2 = d.get("valu_issue_frac_2cyc", 0.0) * scale
+        # vector-instruction issue priced per instruction class at its MEASURED cost (tools/micro/valu_rate.hip; the class counters
+        # and the one assumption about the unnamed rest are in tools/summarize_round.py); without the class pass: 2 cycles each
+        valu_w = d.get("valu_issue_frac_weighted_est", 0.0) * scale
+        valu = valu_w if valu_w > 0.0 else valu2
         clock = d.get("clock_ghz", PEAK_CLOCK_GHZ)
         view["traffic"] = round(d["hbm_side_bytes_per_launch"]) if "hbm_side_bytes_per_launch" in d else None
-        if ta >= valu2:
+        if ta >= valu:
             view["bound"], view["unit"] = "vmem", f"Gcycle/s busy, summed over the {CUS} texture addressers (one per CU)"
             achieved, peak = c["TA_TA_BUSY_sum"] / nd / launch_s / 1e9, CUS * clock
+        elif valu_w > 0.0:
+            view["bound"] = "valu-issue"
+            view["unit"] = (f"Gcycle/s of vector-instruction issue, summed over the {SIMDS} SIMDs: instruction counts by class (PMC) x the measured "
+                            "issue cost of the class (2.33 / 3.85 / 7.3 cycles; the unnamed rest priced slow: an estimate)")
+            achieved, peak = d["valu_issue_cycles_weighted_est"] / nd / launch_s / 1e9, SIMDS * clock
         else:
             view["bound"], view["unit"] = "valu-issue", "G wave64 VALU instructions/s (2 cycles each per SIMD)"
             achieved, peak = c["SQ_INSTS_VALU"] / nd / launch_s / 1e9, SIMDS * clock / 2.0
@@ -420,8 +429,8 @@ def main():
         "segment_kernel": {"launch_ms": round(float(seg_ms.value) / max(1, seg_n.value), 4), "launches": seg_n.value},
         "step_kernel_ms": round(float(kernel_ms.value) / args.steps, 3),
         "note": "bound = the unit with the highest utilisation in the committed PMC passes, rescaled to this run's launch time: "
-                "the vector-memory front end (texture-addresser busy) against VALU issue at 2 cycles per wave64 instruction "
-                "(MI355X_MICROARCH.md). Not HBM: the trees are cache-resident and the path state streams at a third of the HBM "
+                "the vector-memory front end (texture-addresser busy) against vector-instruction issue priced per class at its "
+                "measured cost (pmc.valu_issue_frac_weighted_est; the 2-cycle figure of MI355X_MICROARCH.md is printed beside it). Not HBM: the trees are cache-resident and the path state streams at a third of the HBM "
                 "rate (pmc.hbm_side; traffic = measured L2-miss side per launch; `algorithmic` = unavoidable HBM bytes over the launch time "
                 "against 8 TB/s). pmc.valu_issue_frac_weighted_est prices the instruction classes at their measured issue cost "
                 "(tools/micro/valu_rate.hip: compares, selects, min / max, conversions take 1.65x an fma): by it the vector unit is "
