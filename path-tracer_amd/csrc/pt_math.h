@@ -151,9 +151,18 @@ PT_DEV float pt_acos01(float x) {
 // src/kernel.cu:75-76): the stream of a (pixel, sample) no longer depends on launch shape or on
 // which GPU renders it, which is what makes the spp split across GPUs exact.
 struct u4 { uint32_t x, y, z, w; };
+#ifndef PT_PHILOX_LOCAL_KEYS
+#define PT_PHILOX_LOCAL_KEYS 1
+#endif
 
 PT_DEV u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 	const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#if PT_PHILOX_LOCAL_KEYS
+	// The key is wave-uniform (the master seed), so the twenty round keys are too - and the compiler, seeing them loop-invariant,
+	// kept them in scalar registers across the kernels' main loops, where there is no room: they were spilled to vector lanes
+	// and read back one by one (16 ... 27 v_readlane_b32 per call). Opaque here, they are re-derived per call by scalar adds.
+	asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
 	for (int i = 0; i < 10; ++i) {
 		uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
