@@ -188,7 +188,9 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 			if (x >= cam.width || y >= cam.height) alive = false;
 			const uint32_t pixel = (uint32_t)(x + y * cam.width);
 			const uint32_t sample = (uint32_t)(wp.first_sample + sl);
-			Rad3* rad_slot = wp.rad + (size_t)sl * (size_t)wp.npix + pixel;
+			// (sample, pixel) and (bounce, slot) indices stay below 2^32 records (wf_ensure): 32-bit products, one 64-bit shift-add for
+			// the address, instead of 64-bit multiply-adds per lane
+			Rad3* rad_slot = wp.rad + ((uint32_t)sl * (uint32_t)wp.npix + pixel);
 
 			Ray ray;
 			set_ray(ray, ro, rd);   // shading reads origin and direction only; the inverse is formed once, for the rays that go on
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 			if (leaves) {
 				int* li = sh_lists + (nb * nlists) * WSL_LIST_INTS;
 				const int slot = li[2] + atomicAdd(&li[1], 1);
-				const size_t so = (size_t)nb * wp.set_stride + (size_t)slot;
+				const uint32_t so = (uint32_t)nb * (uint32_t)wp.set_stride + (uint32_t)slot;
 				wp.s0[so] = make_float4(ray.o.x, ray.o.y, ray.o.z, best_dist);
 				wp.s1[so] = make_float4(ray.d.x, ray.d.y, ray.d.z, best_t);
 				wp.s2[so] = make_float4(mask.x, mask.y, mask.z, __int_as_float(best_obj));
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 				for (int L = 1; L < nlists; ++L)
 					if ((flags >> L) & 1u) {
 						const int q = li[L * WSL_LIST_INTS + 2] + atomicAdd(&li[L * WSL_LIST_INTS + 1], 1);
-						wp.queue[L - 1][(size_t)nb * wp.queue_stride + (size_t)q] = slot;
+						wp.queue[L - 1][(uint32_t)nb * (uint32_t)wp.queue_stride + (uint32_t)q] = slot;
 					}
 			}
 			const unsigned long long pm = __ballot(stays);

@@ -248,6 +248,9 @@ static int wf_ensure(PtxCtx* c, size_t paths, size_t rad, int queues, int sets) 
 	if (sets < c->wf_sets) sets = c->wf_sets;
 	wf_free(c);
 	const size_t recs = paths * (size_t)sets;
+	// the segment loop kernel indexes (bounce, slot) and (sample, pixel) in 32 bits; the caller halves the pass on any failure here
+	if (recs >= ((size_t)1 << 32) || rad >= ((size_t)1 << 32) / sizeof(Rad3))
+		return fail(PTX_E_LIMIT, "a pass of %zu paths x %d state sets passes the 32-bit record index", paths, sets);
 	HIP_TRY(hipMalloc((void**)&c->wf.s0, recs * sizeof(float4)));
 	HIP_TRY(hipMalloc((void**)&c->wf.s1, recs * sizeof(float4)));
 	HIP_TRY(hipMalloc((void**)&c->wf.s2, recs * sizeof(float4)));
