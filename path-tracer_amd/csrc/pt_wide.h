@@ -106,7 +106,8 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 			const f3 bd = mk3(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
 			if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 128; x_usteps++; x_units += (uint64_t)take; } }
 			if (on) {   // uniform per quad
-				const float4* bp = tg + ((size_t)grp * PT_GRP_BLOCK_F4 + (lane & 3));
+				// 32-bit byte offset from the (wave-uniform) base: ptx_scene_upload refuses scenes whose groups pass 4 GB
+				const float4* bp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tg) + (grp * (uint32_t)(PT_GRP_BLOCK_F4 * 16) + (uint32_t)((lane & 3) << 4)));
 				const float4 c0 = bp[0], c1 = bp[4], c2 = bp[8], c3 = bp[12], c4 = bp[16];
 				f3x2 va, e1, e2;
 				va.x = (v2f){c0.x, c0.y}; va.y = (v2f){c0.z, c0.w}; va.z = (v2f){c1.x, c1.y};
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		uint32_t gh = 0;          // bit k: child k is a group and the ray touches its box
 		int gref0 = 0, gref1 = 0, gref2 = 0, gref3 = 0;
 		if (state == DESCEND) {
-			const float4* rec = wn + 4 * (size_t)curr;
+			const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wn) + ((uint32_t)curr << 6));   // < 2^24 records: a 32-bit byte offset
 			const float4 f0 = rec[0], f1 = rec[1], f2 = rec[2], f3 = rec[3];
 			const float ax = (f0.x - o.x) * inv.x, ay = (f0.y - o.y) * inv.y, az = (f0.z - o.z) * inv.z;
 			const float sx = f0.w * inv.x, sy = f1.x * inv.y, sz = f1.y * inv.z;

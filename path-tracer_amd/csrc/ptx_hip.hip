@@ -1001,6 +1001,10 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 	}
 	if (wide.empty()) wide.assign(4, make_float4(0, 0, 0, 0));
 	if (wide.size() / 4 >= ((size_t)1 << 24)) return fail(PTX_E_LIMIT, "scene has %zu wide nodes; the limit is 2^24", wide.size() / 4);
+	// the wide traversal addresses node records and triangle groups by 32-bit BYTE offsets from their bases (one shift instead of a
+	// sign extension and two 64-bit operations per fetch): 4 GB of groups = 13.4 million groups = 107 million triangles
+	if (grp_tris.size() * sizeof(float4) >= ((size_t)1 << 32))
+		return fail(PTX_E_LIMIT, "scene has %zu triangle groups; the limit is 2^32 / 320", grp_tris.size() / PT_GRP_BLOCK_F4);
 	if (grp_boxes.size() / 2 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu triangle groups; the limit is 2^26", grp_boxes.size() / 2);
 	// the traversal kernels address node / leaf-half records with 32-bit byte offsets from the array base
 	if (nodes.size() / 4 >= ((size_t)1 << 26)) return fail(PTX_E_LIMIT, "scene has %zu KD node and leaf-half records; the limit is 2^26", nodes.size() / 4);
