@@ -233,7 +233,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 		const uint64_t du1 = dg_unit;
 		// ---- one wide node per descending lane ----
 		if (FLAGS & PT_F_STATS) { if (lane == 0) { tot += 64; x_iters++; } if (state == DESCEND) x_item++; }
-		uint32_t gh = 0;          // bit k: child k is a group and the ray touches its box
+		bool g0 = false, g1 = false, g2 = false, g3 = false;   // child k is a group and the ray touches its box
 		int gref0 = 0, gref1 = 0, gref2 = 0, gref3 = 0;
 		if (state == DESCEND) {
 			const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(wn) + ((uint32_t)curr << 6));   // < 2^24 records: a 32-bit byte offset
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 			const bool h2 = hit(WFW_QB(nx, 2), WFW_QB(ny, 2), WFW_QB(nz, 2), WFW_QB(fx, 2), WFW_QB(fy, 2), WFW_QB(fz, 2), n2) & (r2 != -1);
 			const bool h3 = hit(WFW_QB(nx, 3), WFW_QB(ny, 3), WFW_QB(nz, 3), WFW_QB(fx, 3), WFW_QB(fy, 3), WFW_QB(fz, 3), n3) & (r3 != -1);
 #undef WFW_QB
-			gh = ((h0 & (r0 < 0)) ? 1u : 0u) | ((h1 & (r1 < 0)) ? 2u : 0u) | ((h2 & (r2 < 0)) ? 4u : 0u) | ((h3 & (r3 < 0)) ? 8u : 0u);
+			g0 = h0 & (r0 < 0); g1 = h1 & (r1 < 0); g2 = h2 & (r2 < 0); g3 = h3 & (r3 < 0);
 			// inner children, nearest first: sort (entry distance with the slot in its two lowest bits)
 			auto skey = [](bool on, float tn, uint32_t slot) {
 				return on ? ((__float_as_uint(tn) & ~3u) | slot) : 0xffffffffu;
@@ -311,12 +311,12 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 			}
 		}
 		// append the touched groups to the wave's list (ballot + popcount prefix, no atomics)
-#define WFW_APPEND(BIT, REF) { \
-			const bool on_ = (gh & (BIT)) != 0u; \
+#define WFW_APPEND(ON, REF) { \
+			const bool on_ = (ON); \
 			const unsigned long long m_ = __ballot(on_); \
 			if (on_) units[nunits + (int)__popcll(m_ & lt)] = (uint32_t)lane | (((uint32_t)(REF) & 0x03ffffffu) << 6); \
 			nunits += (int)__popcll(m_); }
-		WFW_APPEND(1u, gref0) WFW_APPEND(2u, gref1) WFW_APPEND(4u, gref2) WFW_APPEND(8u, gref3)
+		WFW_APPEND(g0, gref0) WFW_APPEND(g1, gref1) WFW_APPEND(g2, gref2) WFW_APPEND(g3, gref3)
 #undef WFW_APPEND
 		if (nunits >= DRAIN_MIN) unit_steps(false);
 		dg_visit += (WFW_CLOCK() - ct1) - (dg_unit - du1);
