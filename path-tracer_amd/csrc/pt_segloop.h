@@ -57,6 +57,9 @@
 // loop of leaf_only_mesh_pairs fetches them per lane (6 x 16 B per touched pair, each a line of its own for the L1) in a
 // chain of dependent loads. 16 triangles = 768 B: 5.60 -> 5.50 ms per launch; with 32 (1.5 KB) the workgroup's LDS passes
 // what five workgroups per CU can have and the kernel runs at 6.24 ms. Scenes with more fall back to tri_geom.
+#ifndef WSL_CAM_LDS
+#define WSL_CAM_LDS 1
+#endif
 #ifndef WSL_LDS_TRIS
 #define WSL_LDS_TRIS 16
 #endif
@@ -119,6 +122,22 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 			}
 		}
 	}
+#if WSL_CAM_LDS
+	// What primary-ray generation needs of the camera, derived once per workgroup (the same operations in the same order as
+	// pixel_midpoint / jittered_dir, pt_kernels.h) and read back from LDS where a ray is generated: as kernel arguments these two
+	// dozen wave-uniform values sat in scalar registers across the whole loop, and this kernel has none to spare (79 spilled).
+	__shared__ float sh_cam[24];
+	if (tid == 0) {
+		const f3 sdv = cam.screen_dist * normalize3(mk3(cam.dir[0], cam.dir[1], cam.dir[2]));
+		const f3 rn = normalize3(mk3(cam.right[0], cam.right[1], cam.right[2])), un = normalize3(mk3(cam.up[0], cam.up[1], cam.up[2]));
+		sh_cam[0] = sdv.x; sh_cam[1] = sdv.y; sh_cam[2] = sdv.z; sh_cam[3] = cam.pixel_size;
+		sh_cam[4] = rn.x; sh_cam[5] = rn.y; sh_cam[6] = rn.z; sh_cam[7] = cam.pixel_size / 2.0f;
+		sh_cam[8] = un.x; sh_cam[9] = un.y; sh_cam[10] = un.z; sh_cam[11] = cam.half_x;
+		sh_cam[12] = cam.pos[0]; sh_cam[13] = cam.pos[1]; sh_cam[14] = cam.pos[2]; sh_cam[15] = cam.half_y;
+		sh_cam[16] = cam.right[0]; sh_cam[17] = cam.right[1]; sh_cam[18] = cam.right[2]; sh_cam[19] = cam.pixel_size * cam.aa_jitter;
+		sh_cam[20] = cam.up[0]; sh_cam[21] = cam.up[1]; sh_cam[22] = cam.up[2]; sh_cam[23] = 0.0f;
+	}
+#endif
 	__shared__ int sh_pool_cur;
 	if (tid == 0) { sh_pool = 0; sh_live = 0; }
 	bool exhausted = n_in <= 0;   // block-uniform: the input has no entry left to claim
@@ -198,9 +217,22 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 			int shade_type = -1;
 			if (alive) {
 				if (bs < 0) {
+#if WSL_CAM_LDS
+					// pixel_midpoint + jittered_dir (reference: src/pathtracing.cu:84-92, 121-126) on the values derived above
+					const float4* cl = reinterpret_cast<const float4*>(sh_cam);
+					const float4 c0 = cl[0], c1 = cl[1], c2 = cl[2], c3 = cl[3], c4 = cl[4], c5 = cl[5];
+					const float ps = c0.w;
+					const f3 sdv = mk3(c0.x, c0.y, c0.z), cpos = mk3(c3.x, c3.y, c3.z);
+					const f3 pv = (c2.w - (float)x * ps - c1.w) * mk3(c1.x, c1.y, c1.z) + (c3.w - (float)y * ps - c1.w) * mk3(c2.x, c2.y, c2.z);
+					const f3 mid = cpos + sdv + pv;
+					const u4 jr = philox4x32_10(pixel, sample, PT_DIM_JITTER, 0u, wp.k0, wp.k1);
+					const float jx = c4.w * (u01(jr.x) - 0.5f), jy = c4.w * (u01(jr.y) - 0.5f);
+					init_ray(ray, cpos, normalize3(mid + jx * mk3(c4.x, c4.y, c4.z) + jy * mk3(c5.x, c5.y, c5.z) - cpos));
+#else
 					f3 mid, centre;
 					pixel_midpoint(cam, x, y, mid, centre);
 					init_ray(ray, cam_pos, jittered_dir(cam, mid, pixel, sample, wp.k0, wp.k1));
+#endif
 					if (maxb == 0) {   // max_ray_bounces == 0: the bounce loop never runs
 						*rad_slot = Rad3{0.0f, 0.0f, 0.0f};
 						n_paths++;
