@@ -84,7 +84,9 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 	const int nlists = 1 + wp.num_big;
 	const int nl_total = (maxb > 0 ? maxb : 1) * nlists;
 	const int n_in = launch_bounce == 0 ? wp.n_total : WF_CNT(wp, launch_bounce - 1, 0);
+#if !WSL_CAM_LDS
 	const f3 cam_pos = mk3(cam.pos[0], cam.pos[1], cam.pos[2]);
+#endif
 	const size_t in_off = launch_bounce > 0 ? (size_t)(launch_bounce - 1) * wp.set_stride : 0;
 	const float4* __restrict__ i0 = wp.s0 + in_off;
 	const float4* __restrict__ i1 = wp.s1 + in_off;
