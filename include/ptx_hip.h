@@ -252,6 +252,8 @@ int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches,
  *                     cost, of 1 = the tree collapsed from the reference's KD tree and 2 = one built by the surface-area heuristic
  *   "seg_mode"        1 (default) segment kernel with the bounce loop inside the launch (pt_segloop.h), 0 = one bounce per launch
  *   "seg_blocks"      workgroups per CU of the segment launches
+ *   "seg_compact"     [PTX_SEG_COMPACT] 1 (default) = 13-word LDS pool entries where they fit (bounce limit <= 7, <= 254 objects,
+ *                     < 2^21 - 1 triangles): six workgroups per CU instead of five; 0 = always the 15-word entries
  *   "grp_mode", "grp_pad_ppm"  how leaf triangles are cut into groups of eight and how far their boxes are padded (parts per
  *                     million of the mesh diagonal, on top of 5e-5); read by the NEXT ptx_scene_upload
  *   "seg_lds_tables"  material / texture-descriptor tables of the segment kernel in LDS: 0 never, 1 (default) for the per-bounce kernel only

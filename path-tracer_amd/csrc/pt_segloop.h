@@ -63,13 +63,22 @@
 #ifndef WSL_LDS_TRIS
 #define WSL_LDS_TRIS 16
 #endif
-template <int FLAGS, int LDSTAB>
-__global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevScene sc, DevCamera cam, WfParams wp) {
+// COMPACT: pool entries of 13 words instead of 15 - the hit POINT instead of origin and t (shading reads nothing else of the old
+// ray), and bounce, object and triangle in one word (3 + 8 + 21 bits: the host picks this variant for bounce limits <= 7, < 255
+// objects, < 2^21 - 1 triangles) - and no LDS copy of the cheap triangles: 26.9 KB per workgroup, SIX workgroups per CU instead of five.
+#define WSL_WORDS_COMPACT 13
+#define WSL_COMPACT_MAX_BOUNCES 7
+#define WSL_COMPACT_MAX_OBJECTS 254
+#define WSL_COMPACT_MAX_TRIS ((1 << 21) - 2)
+template <int FLAGS, int LDSTAB, int COMPACT>
+__global__ __launch_bounds__(PT_BLOCK, COMPACT ? 6 : WSL_OCC) void wf_segment_loop_kernel(DevScene sc, DevCamera cam, WfParams wp) {
 	const int tid = threadIdx.x, lane = tid & 63;
 	constexpr int CAP = WF_ROUNDS * PT_BLOCK;
+	constexpr int WORDS = COMPACT ? WSL_WORDS_COMPACT : WSL_WORDS;
+	constexpr int W_U = COMPACT ? 11 : 13, W_V = COMPACT ? 12 : 14;   // where a pool entry keeps u and v
 	__shared__ float4 sh_mats[LDSTAB ? 3 * WF_LDS_MATS : 1];
 	__shared__ DevTexture sh_texs[LDSTAB ? WF_LDS_TEXS : 1];
-	__shared__ float sh_w[WSL_WORDS][CAP];
+	__shared__ float sh_w[WORDS][CAP];
 	__shared__ int sh_live, sh_pool, sh_fresh_base, sh_fresh_n;
 	extern __shared__ int sh_lists[];   // [nl_total][WSL_LIST_INTS]
 	if (LDSTAB) {
@@ -100,9 +109,9 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 	uint64_t sc0 = 0, sc1 = 0, sc2 = 0, sc3 = 0;
 
 	// single-leaf meshes: runs (rounded up to pairs: the slot behind an odd run is tri_geom's zero record) copied in object order
-	__shared__ float4 sh_tri[3 * WSL_LDS_TRIS];
-	bool tris_in_lds = WSL_LDS_TRIS > 0;
-	{
+	__shared__ float4 sh_tri[COMPACT ? 1 : 3 * WSL_LDS_TRIS];
+	bool tris_in_lds = WSL_LDS_TRIS > 0 && !COMPACT;
+	if (!COMPACT) {
 		int total = 0;
 		for (int oi = 0; oi < sc.num_objects; ++oi) {
 			const DevObject& ob = sc.objects[oi];
@@ -177,16 +186,25 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 			int best_obj = -1, best_tri = -1;
 			float best_t = 0.0f, b_u = 0.0f, b_v = 0.0f;
 			f3 ro = mk3(0.0f), rd = mk3(1.0f), mask = mk3(1.0f);
+			f3 hp = mk3(0.0f);   // COMPACT: the hit point, formed where the hit was found (same expression, same bits)
 			if (pooled) {
-				ro = mk3(sh_w[0][e], sh_w[1][e], sh_w[2][e]);
+				ro = mk3(sh_w[0][e], sh_w[1][e], sh_w[2][e]);   // COMPACT: the hit point
 				rd = mk3(sh_w[3][e], sh_w[4][e], sh_w[5][e]);
 				mask = mk3(sh_w[6][e], sh_w[7][e], sh_w[8][e]);
 				path = shi[9 * CAP + e];
 				const int meta = shi[10 * CAP + e];
-				bs = meta & 0xff;
-				best_obj = (meta >> 8) - 1;
-				best_tri = shi[11 * CAP + e];
-				best_t = sh_w[12][e]; b_u = sh_w[13][e]; b_v = sh_w[14][e];
+				if (COMPACT) {
+					hp = ro;
+					bs = meta & 7;
+					best_obj = ((meta >> 3) & 0xff) - 1;
+					best_tri = (int)((uint32_t)meta >> 11) - 1;
+				} else {
+					bs = meta & 0xff;
+					best_obj = (meta >> 8) - 1;
+					best_tri = shi[11 * CAP + e];
+					best_t = sh_w[12][e];
+				}
+				b_u = sh_w[W_U][e]; b_v = sh_w[W_V][e];
 			} else if (fresh) {
 				const int i = fresh_base + (e - n_pool);
 				if (launch_bounce == 0) path = i;
@@ -197,6 +215,7 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 					best_obj = __float_as_int(a2.w);
 					best_tri = __float_as_int(a3.x); b_u = a3.y; b_v = a3.z;
 					path = __float_as_int(a3.w);
+					if (COMPACT) hp = ro + rd * best_t;
 				}
 			}
 			__syncthreads();   // this round's pool entries are in registers: stage A may overwrite them
@@ -253,7 +272,7 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 						held.s0 = held.s1 = held.s2 = held.s3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 						hi.object = best_obj;
 						hi.dist = 0.0f;   // not read by the shading
-						hi.point = ray.o + ray.d * best_t;
+						hi.point = COMPACT ? hp : ray.o + ray.d * best_t;
 						if (ob.type == 0) {
 							hi.tri = -1;
 							hi.bary = mk3(0.0f);
@@ -433,13 +452,20 @@ __global__ __launch_bounds__(PT_BLOCK, WSL_OCC) void wf_segment_loop_kernel(DevS
 				base = __builtin_amdgcn_readfirstlane(base);
 				if (stays) {
 					const int p = base + (int)__popcll(pm & ((1ull << lane) - 1ull));
-					sh_w[0][p] = ray.o.x; sh_w[1][p] = ray.o.y; sh_w[2][p] = ray.o.z;
+					// COMPACT: the hit point in place of the origin (hi.point of the shading: ray.o + ray.d * best_t, formed here)
+					const f3 w0 = COMPACT ? ray.o + ray.d * best_t : ray.o;
+					sh_w[0][p] = w0.x; sh_w[1][p] = w0.y; sh_w[2][p] = w0.z;
 					sh_w[3][p] = ray.d.x; sh_w[4][p] = ray.d.y; sh_w[5][p] = ray.d.z;
 					sh_w[6][p] = mask.x; sh_w[7][p] = mask.y; sh_w[8][p] = mask.z;
 					shi[9 * CAP + p] = path;
-					shi[10 * CAP + p] = nb | ((best_obj + 1) << 8);
-					shi[11 * CAP + p] = best_tri;
-					sh_w[12][p] = best_t; sh_w[13][p] = b_u; sh_w[14][p] = b_v;
+					if (COMPACT) {
+						shi[10 * CAP + p] = (int)((uint32_t)nb | ((uint32_t)(best_obj + 1) << 3) | ((uint32_t)(best_tri + 1) << 11));
+					} else {
+						shi[10 * CAP + p] = nb | ((best_obj + 1) << 8);
+						shi[11 * CAP + p] = best_tri;
+						sh_w[12][p] = best_t;
+					}
+					sh_w[W_U][p] = b_u; sh_w[W_V][p] = b_v;
 				}
 			}
 		} // chunks

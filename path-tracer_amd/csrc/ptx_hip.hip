@@ -58,7 +58,7 @@ struct PtxCtx {
 	int wf_batch;              // samples per wavefront pass
 	bool force_megakernel;
 	int trav_variant, trav_blocks_per_cu;   // tuning knobs (env PTX_TRAV_VARIANT / PTX_TRAV_BLOCKS)
-	int wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu, wide_build;
+	int wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu, wide_build, seg_compact;
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
@@ -127,7 +127,7 @@ static int env_int(const char* name, int dflt) {
 #endif
 
 struct Tuning {
-	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu, wide_build;
+	int wf_batch, trav_variant, trav_blocks_per_cu, grp_pad_ppm, wide_scap, grp_mode, seg_lds_tables, wide_margin_ppm, seg_mode, seg_blocks_per_cu, wide_build, seg_compact;
 	bool force_megakernel;
 };
 
@@ -153,6 +153,7 @@ static Tuning tuning_defaults() {
 	// segment kernel: 1 = bounce loop inside the launch (pt_segloop.h), 0 = one bounce per launch (wf_segment_kernel)
 	t.seg_mode = clampi(env_int("PTX_SEG_MODE", 1), 0, 1);
 	t.seg_blocks_per_cu = clampi(env_int("PTX_SEG_BLOCKS", 16), 1, 64);
+	t.seg_compact = clampi(env_int("PTX_SEG_COMPACT", 1), 0, 1);
 	// margin of the wide traversal's distance culling, relative to the best t (and absolute), in parts per million (pt_wide.h)
 	t.wide_margin_ppm = clampi(env_int("PTX_WIDE_MARGIN_PPM", 10000), 0, 1000000);
 	t.wide_scap = clampi(env_int("PTX_WIDE_SCAP", WFW_SCAP_MAX), 1, 32);
@@ -172,6 +173,7 @@ static void tune_defaults(PtxCtx* c) {
 	c->seg_lds_tables = t.seg_lds_tables;
 	c->seg_mode = t.seg_mode;
 	c->seg_blocks_per_cu = t.seg_blocks_per_cu;
+	c->seg_compact = t.seg_compact;
 	c->wide_scap = t.wide_scap;
 	c->wide_build = t.wide_build;
 }
@@ -192,6 +194,7 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	else if (!strcmp(key, "seg_lds_tables")) ctx->seg_lds_tables = value < 0 ? d.seg_lds_tables : clampi(value, 0, 2);
 	else if (!strcmp(key, "seg_mode")) ctx->seg_mode = value < 0 ? d.seg_mode : clampi(value, 0, 1);
 	else if (!strcmp(key, "seg_blocks")) ctx->seg_blocks_per_cu = value < 0 ? d.seg_blocks_per_cu : clampi(value, 1, 64);
+	else if (!strcmp(key, "seg_compact")) ctx->seg_compact = value < 0 ? d.seg_compact : clampi(value, 0, 1);
 	else if (!strcmp(key, "wide_margin_ppm")) ctx->wide_margin_ppm = value < 0 ? d.wide_margin_ppm : clampi(value, 0, 1000000);
 	else if (!strcmp(key, "wide_scap")) ctx->wide_scap = value < 0 ? d.wide_scap : clampi(value, 1, 32);
 	else if (!strcmp(key, "wide_build")) ctx->wide_build = value < 0 ? d.wide_build : clampi(value, 0, 2);
@@ -1326,12 +1329,17 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				wp.s0 = ctx->wf.s0; wp.s1 = ctx->wf.s1; wp.s2 = ctx->wf.s2; wp.s3 = ctx->wf.s3;
 				for (int k = 0; k < scene->num_big; ++k) wp.queue[k] = ctx->wf.queue[k];
 				const size_t dyn = WSL_DYN_BYTES(maxb, 1 + scene->num_big);
+				// 13-word pool entries (six workgroups per CU) where bounce, object and triangle fit one word (pt_segloop.h)
+				const bool compact = ctx->seg_compact != 0 && maxb <= WSL_COMPACT_MAX_BOUNCES && scene->num_objects <= WSL_COMPACT_MAX_OBJECTS &&
+				                     scene->dev.num_tris <= WSL_COMPACT_MAX_TRIS && dyn <= 256;
 				if (collect_stats)
-					hipLaunchKernelGGL((wf_segment_loop_kernel<PT_F_STATS, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
+					hipLaunchKernelGGL((wf_segment_loop_kernel<PT_F_STATS, 0, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
 				else if (lds_tables)
-					hipLaunchKernelGGL((wf_segment_loop_kernel<0, 1>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
+					hipLaunchKernelGGL((wf_segment_loop_kernel<0, 1, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
+				else if (compact)
+					hipLaunchKernelGGL((wf_segment_loop_kernel<0, 0, 1>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
 				else
-					hipLaunchKernelGGL((wf_segment_loop_kernel<0, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
+					hipLaunchKernelGGL((wf_segment_loop_kernel<0, 0, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
 			} else {
 				const size_t in_set = (size_t)((bounce & 1) ^ 1);
 				wp.s0 = ctx->wf.s0 + out_set * stride; wp.s1 = ctx->wf.s1 + out_set * stride; wp.s2 = ctx->wf.s2 + out_set * stride; wp.s3 = ctx->wf.s3 + out_set * stride;
