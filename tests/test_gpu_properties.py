@@ -37,9 +37,19 @@ def test_full_size_sample_ranges_compose_and_schedules_agree(pt, ctx):
         _tune(pt, ctx, b"megakernel", 0)
         wf, sw = gpuops.render(ctx, scene, cam, 0, 1, 11)
         assert np.array_equal(mk.view(np.uint32), wf.view(np.uint32)) and sm.rays == sw.rays
+        # the segment kernel's pool layouts (13-word entries, six workgroups per CU, against the 15-word ones) and the
+        # per-bounce kernel: three schedules of the same arithmetic
+        for key, val in ((b"seg_compact", 0), (b"seg_mode", 0)):
+            _tune(pt, ctx, key, val)
+            acc, s = gpuops.render(ctx, scene, cam, 0, 4, 11)
+            _tune(pt, ctx, key, -1)
+            assert np.array_equal(base.view(np.uint32), acc.view(np.uint32)), f"{key} {val}"
+            assert s.rays == st.rays
     finally:
         _tune(pt, ctx, b"wf_batch", -1)
         _tune(pt, ctx, b"megakernel", -1)
+        _tune(pt, ctx, b"seg_compact", -1)
+        _tune(pt, ctx, b"seg_mode", -1)
     # determinism: same call twice
     again, _ = gpuops.render(ctx, scene, cam, 0, 4, 11)
     assert np.array_equal(base.view(np.uint32), again.view(np.uint32))
