@@ -65,7 +65,8 @@
 //              pair in q0.y (int). A lane tests the boxes (wave-uniform data) and then only the pairs it touches,
 //              in run order: a ray inside the sky cube tests one face instead of twelve triangles.
 //   wide_nodes the 4-wide tree over the groups that the wide traversal walks (pt_wide.h): 64 B per node = the four child
-//              boxes in the grp_qbox form (f0..f2) + int4 links (>= 0 node, 0x80000000 | group, -1 none); children
+//              boxes in the grp_qbox form (f0..f2), but with the 24 code bytes AXIS-major (word 2k = the four lo codes of
+//              axis k, word 2k + 1 the four hi codes, child g in byte g) + int4 links (>= 0 node, 0x80000000 | group, -1 none); children
 //              that are nodes come first and have consecutive indices. wide_root[object] = its root (-1: none).
 //   tri_shade  4 x float4 per triangle (64 B), same order, touched once per mesh hit:
 //                s0 = (na.xyz, ta.x) s1 = (nb.xyz, ta.y) s2 = (nc.xyz, tb.x)
