@@ -434,7 +434,7 @@ def main():
                 "rate (pmc.hbm_side; traffic = measured L2-miss side per launch; `algorithmic` = unavoidable HBM bytes over the launch time "
                 "against 8 TB/s). pmc.valu_issue_frac_weighted_est prices the instruction classes at their measured issue cost "
                 "(tools/micro/valu_rate.hip: compares, selects, min / max, conversions take 1.65x an fma): by it the vector unit is "
-                "the close second limit of both kernels (DESIGN.md 3.4)",
+                "the first limit of the traversal and ties with the vector-memory front end in the segment kernel (DESIGN.md 3.4)",
     })
 
     # ---- CPU baseline leg (rank 0): the oracle, bounded sample of the same workload ------------------
