@@ -161,3 +161,93 @@ def test_oracle_render_properties(pt, orc):
     _, cam0 = pt.load_scene("geoms", width=48, height=36, upload=False, bounces=0)
     z, st0 = orc.render(desc, cam0, 0, 2, 9)
     assert z.max() == 0 and st0.rays == 0
+
+
+def test_oracle_bsdfs_obey_the_optics_they_restate(pt, orc):
+    """The oracle's three BSDFs (reference: src/surfaces.cuh:14-137) against their definitions in float64 - an
+    independent statement of WHAT they compute, not of how: sampled directions are unit vectors inside the stated cone
+    about the stated axis, new origins are the hit point moved along the normal by the reference's biases, the
+    refracted direction obeys Snell's law, and the refractive mask factors are the Schlick / energy ratios."""
+    rng = np.random.default_rng(7)
+    n = 3000
+    cases = (pt.PtxBsdfCase * n)()
+
+    def unit(v):
+        return v / np.linalg.norm(v)
+
+    spec = []
+    for i in range(n):
+        c = cases[i]
+        nrm = unit(rng.normal(size=3))
+        d = unit(rng.normal(size=3))
+        if np.dot(d, nrm) > 0 and i % 3 != 2:   # rays arrive from outside for the opaque materials
+            d = d - 2 * np.dot(d, nrm) * nrm
+        pnt = rng.uniform(-5, 5, 3)
+        mt = 1 + i % 3
+        refl, ior, sharp = rng.uniform(0.05, 0.95), rng.uniform(1.1, 2.0), rng.uniform(0.0, 1.0)
+        u = rng.uniform(1e-3, 1.0, 4)
+        for k in range(3):
+            c.dir[k], c.normal[k], c.point[k] = d[k], nrm[k], pnt[k]
+        c.mat_type, c.reflect_factor, c.refract_index, c.sharpness = mt, refl, ior, sharp
+        for k in range(4):
+            c.u[k] = u[k]
+        spec.append((np.float32(d).astype(np.float64), np.float32(nrm).astype(np.float64), np.float32(pnt).astype(np.float64),
+                     mt, float(np.float32(refl)), float(np.float32(ior)), float(np.float32(sharp)), np.float32(u).astype(np.float64)))
+    assert orc.lib().orc_bsdf_eval(n, cases) == 0
+    seen = {1: 0, 2: 0, 3: 0, "tir": 0, "refr": 0, "refl": 0}
+    for i, (d, nrm, pnt, mt, refl, ior, sharp, u) in enumerate(spec):
+        c = cases[i]
+        od, oo, om = np.array(c.out_dir[:], np.float64), np.array(c.out_origin[:], np.float64), np.array(c.out_mask[:], np.float64)
+        assert abs(np.linalg.norm(od) - 1.0) < 1e-5, i
+        if mt == 1:   # Diffuse_BRDF: cosine-ish cone of half-angle pi/2 about the normal, origin + 5e-5 n
+            assert np.dot(od, nrm) > -1e-3, i
+            assert np.allclose(oo, pnt + 5e-5 * nrm, atol=2e-6), i
+            assert np.array_equal(om, [1, 1, 1])
+            seen[1] += 1
+        elif mt == 2:   # Specular_Diffuse_BRDF: u0 > reflect_factor -> diffuse; else a cone about the mirror direction
+            if u[0] > refl:
+                assert np.dot(od, nrm) > -1e-3 and np.allclose(oo, pnt + 5e-5 * nrm, atol=2e-6), i
+            else:
+                mirror = d - 2 * np.dot(nrm, d) * nrm
+                max_cone = (np.pi / 2) * (1.0 - sharp)
+                scatt = np.pi / 2 - np.arccos(min(1.0, abs(np.dot(d, nrm))))
+                ang = min(max_cone, scatt)
+                # rand_cone_Dir: sin of the deviation is at most sqrt(sin(ang)) (r^2 = sin(ang) * u, |offset| = r, w = sqrt(1 - r^2 + 1e-4))
+                cosdev = np.dot(od, mirror)
+                assert cosdev > np.sqrt(max(0.0, 1.0 - np.sin(ang))) - 2e-3, (i, cosdev, ang)
+                assert np.allclose(oo, pnt + 1e-4 * nrm, atol=2e-6), i
+            seen[2] += 1
+        else:   # Refractive_BRDF
+            n_or = nrm if np.dot(nrm, d) < 0 else -nrm
+            outside = np.dot(nrm, n_or) > 0
+            nn = (1.0 / ior) if outside else ior
+            cos_ray = np.dot(d, n_or)
+            cos2 = 1.0 - nn * nn * (1.0 - cos_ray * cos_ray)
+            mirror = d - 2 * np.dot(n_or, d) * n_or
+            if cos2 < 0:   # total internal reflection
+                assert np.allclose(od, mirror, atol=2e-5) and np.allclose(oo, pnt + 0.05 * n_or, atol=2e-5), i
+                assert np.array_equal(om, [1, 1, 1])
+                seen["tir"] += 1
+            else:
+                refl0 = ((ior - 1.0) / (ior + 1.0)) ** 2
+                # transmitted direction by Snell: n1 sin(i) = n2 sin(t), in the plane of incidence, on the far side
+                trans = unit(d * nn - nrm * ((1.0 if outside else -1.0) * (cos_ray * nn + np.sqrt(cos2))))
+                pw = 1.0 - (-cos_ray if outside else np.dot(trans, nrm))
+                reflectance = refl0 + (1.0 - refl0) * pw ** 5
+                energy = refl + (1.0 - 2.0 * refl) * reflectance
+                if u[0] < refl:
+                    assert np.allclose(od, d - 2 * np.dot(nrm, d) * nrm, atol=2e-5), i
+                    assert np.allclose(om, reflectance / energy, rtol=2e-4), i
+                    assert np.allclose(oo, pnt + 0.05 * n_or, atol=2e-5), i
+                    seen["refl"] += 1
+                else:
+                    assert np.allclose(od, trans, atol=2e-5), i
+                    sin_i, sin_t = np.linalg.norm(np.cross(d, n_or)), np.linalg.norm(np.cross(od, n_or))
+                    assert abs(sin_t - nn * sin_i) < 2e-5, i   # Snell
+                    assert np.dot(od, n_or) < 0, i
+                    assert np.allclose(om, (1.0 - reflectance) / (1.0 - energy), rtol=2e-4), i
+                    assert np.allclose(oo, pnt - 0.0005 * n_or, atol=2e-5), i
+                    seen["refr"] += 1
+            seen[3] += 1
+    assert min(seen[1], seen[2], seen["refr"], seen["refl"]) > 50 and seen["tir"] > 5, seen
+
