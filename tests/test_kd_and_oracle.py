@@ -251,3 +251,41 @@ def test_oracle_bsdfs_obey_the_optics_they_restate(pt, orc):
             seen[3] += 1
     assert min(seen[1], seen[2], seen["refr"], seen["refl"]) > 50 and seen["tir"] > 5, seen
 
+
+def test_oracle_sphere_hits_agree_with_the_quadratic(pt, orc):
+    """testSphereIntersection (reference: src/intersect.cuh:59-83) against the quadratic solved in float64: nearest root
+    beyond the 1e-4 epsilon, else the far one; point on the sphere, normal radial."""
+    desc, cam = pt.load_scene("geoms", width=64, height=48, upload=False)
+    o, d = orc.generate_rays(cam, 1, 5)
+    checked = 0
+    for oi in range(desc.contents.num_objects):
+        ob = desc.contents.objects[oi]
+        if ob.type != 0:
+            continue
+        h = orc.trace(desc, o, d, oi)
+        c, r = np.array(ob.position[:], np.float64), float(ob.radius)
+        for i in range(0, len(o), 3):
+            oo, dd = o[i].astype(np.float64), d[i].astype(np.float64)
+            op = c - oo
+            b = np.dot(op, dd)
+            disc = b * b - np.dot(op, op) + r * r
+            if disc < -1e-6 * r * r:
+                assert h["hit"][i] == 0, (oi, i)
+                continue
+            if disc < 1e-6 * r * r:
+                continue   # tangent within float noise
+            t = b - np.sqrt(disc)
+            if t < 1e-4:
+                t = b + np.sqrt(disc)
+            if abs(t - 1e-4) < 1e-5:
+                continue
+            if t < 1e-4:
+                assert h["hit"][i] == 0, (oi, i)
+                continue
+            assert h["hit"][i] == 1, (oi, i)
+            p = oo + t * dd
+            assert np.allclose(h["point"][i].view(np.float32), p, atol=2e-3 * max(1.0, t)), (oi, i)
+            assert np.allclose(h["normal"][i].view(np.float32), (p - c) / r, atol=2e-3), (oi, i)
+            checked += 1
+    assert checked > 30
+
