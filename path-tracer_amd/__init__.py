@@ -227,8 +227,9 @@ def load_scene(name_or_path, width=0, height=0, textures=-1, preview=0, aabb=-1,
     if not os.path.isabs(path) and not os.path.exists(path):
         path = os.path.join(REPO_ROOT, "scenes", f"scene_{name_or_path}.json")
     H.pth_set_device_upload(1 if upload else 0)
-    if car_tris is not None:
-        H.pth_set_procedural_car_triangles(int(car_tris))
+    # (the host keeps the budget of the procedural stand-in car between loads: always say it, so that a reduced car of one
+    # caller does not become the next caller's headline mesh)
+    H.pth_set_procedural_car_triangles(int(car_tris) if car_tris is not None else 400000)
     rc = H.pth_scene_load(path.encode(), width, height, textures, preview, aabb, bounces)
     if rc != PTX_OK:
         raise RuntimeError(f"scene load failed: {H.pth_last_error().decode(errors='replace')} / "

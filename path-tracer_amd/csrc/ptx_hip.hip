@@ -143,7 +143,7 @@ static Tuning tuning_defaults() {
 	t.wf_batch = clampi(env_int("PTX_WF_BATCH", 128), 1, 256);
 	t.force_megakernel = env_int("PTX_MEGAKERNEL", 0) != 0;
 	t.trav_variant = env_int("PTX_TRAV_VARIANT", 0);
-	if (t.trav_variant != 7 && t.trav_variant != 9 && t.trav_variant != 14 && t.trav_variant != 15) t.trav_variant = 0;
+	if (t.trav_variant != 7 && t.trav_variant != 9 && t.trav_variant != 13 && t.trav_variant != 14 && t.trav_variant != 15) t.trav_variant = 0;
 	t.trav_blocks_per_cu = clampi(env_int("PTX_TRAV_BLOCKS", 16), 1, 64);
 	// padding of the group boxes (pt_scene.h) relative to the mesh diagonal, in parts per million; read at scene upload
 	t.grp_pad_ppm = clampi(env_int("PTX_GRP_PAD_PPM", PT_GRP_PAD_PPM_DEFAULT), 0, 1000000);
@@ -182,8 +182,8 @@ extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	if (!ctx || !key) return fail(PTX_E_INVALID, "ptx_ctx_tune: NULL argument");
 	const Tuning d = tuning_defaults();
 	if (!strcmp(key, "trav_variant")) {
-		if (value >= 0 && value != 0 && value != 7 && value != 9 && value != 14 && value != 15)
-			return fail(PTX_E_INVALID, "ptx_ctx_tune: trav_variant %d is not in this build (0, 7, 9, 14, 15)", value);
+		if (value >= 0 && value != 0 && value != 7 && value != 9 && value != 13 && value != 14 && value != 15)
+			return fail(PTX_E_INVALID, "ptx_ctx_tune: trav_variant %d is not in this build (0, 7, 9, 13, 14, 15)", value);
 		ctx->trav_variant = value < 0 ? d.trav_variant : value;
 	}
 	else if (!strcmp(key, "trav_blocks")) ctx->trav_blocks_per_cu = value < 0 ? d.trav_blocks_per_cu : clampi(value, 1, 64);
@@ -1185,11 +1185,17 @@ static int check_scene(const PtxCtx* ctx, const PtxScene* scene, const char* who
 }
 
 // One traversal launch of the wavefront pipeline: the rays queued for multi-node mesh `obj` (queue k).
-//   trav_variant 0 (default)  the wide traversal (pt_wide.h), then the exact kernel over its retry queue
+//   trav_variant 0 (default)  the wide traversal (pt_wide.h), then the STRICT kernel over its retry queue
 //                14           the same, counted by the wide kernel's own counting twin
-//                15           the exact kernel alone: wf_traverse_coop_kernel, leaf mode 9 = the reference's visiting order
-//                7, 9         the exact kernel with whole leaves per step (leaf modes 3, 4): what trees too deep for the LDS
-//                             areas of mode 9 fall back to; selectable so that the fall-backs are tested on ordinary scenes
+//                15           the STRICT kernel alone: wf_traverse_coop_kernel in the reference's visiting order, testing EVERY triangle
+//                             of every leaf it visits (leaf mode 4, or 3 when the tree's stack leaves no LDS for 4's staging area):
+//                             the reference's test set, so also the hits its triangle test accepts out of rounding noise
+//                7, 9         the strict kernel in leaf mode 3 / 4 by name (so that both are tested on ordinary scenes)
+//                13           the reference's visiting order with GROUPED leaves (leaf mode 9: a leaf's triangles in groups of eight
+//                             with a padded box each, only touched groups tested): 1.75 x as fast as 15, and like the wide
+//                             traversal blind to a noise hit on a triangle whose group box the ray misses (7 of 19.7 million
+//                             adversarial rays, tools/grazing_rate.py; until late round 3 this was what 15 selected and what the
+//                             retry queue ran). Still the counting twin: its counters are the reference's by construction
 // (Rounds 1-2 carried thirteen more A/B variants - one ray per lane, leaf modes 0-2 and 5-8, the unified item loop, probe
 // builds of the wide kernel; their measurements are in DESIGN.md 3.2, their code is in the history.)
 static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams& wp, int obj, int k, int collect_stats) {
@@ -1209,7 +1215,8 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
 	// the exact kernel in the best leaf mode the tree's stack leaves LDS for (or the one a test asks for)
 	auto exact = [&](const WfParams& wp, size_t tb, bool stats) {
-		const int mode = ctx->trav_variant == 7 ? 3 : ctx->trav_variant == 9 ? 4 : 9;
+		// strict (4, else 3) unless the grouped kernel is asked for by name, or counters are collected (same counters, faster)
+		const int mode = ctx->trav_variant == 7 ? 3 : ctx->trav_variant == 9 ? 4 : (ctx->trav_variant == 13 || stats) ? 9 : 4;
 		if (stats) {
 			if (mode == 9 && grp_fits) COOP(PT_F_STATS, 4, WF_CHUNK, WF_ATHRESH, 9);
 			else if (mode != 3 && stage_fits) COOP(PT_F_STATS, 4, 64, 32, 4);

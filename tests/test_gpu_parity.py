@@ -145,7 +145,7 @@ def test_full_size_lamborghini_matches_oracle(pt, orc, ctx):
     gpuops.render_init(ctx, cam)
     acc_o, st_o = orc.render(desc, cam, 3, 1, 7, nthreads=16)
     try:
-        for variant in (0, 7, 9, 14, 15):
+        for variant in (0, 7, 9, 13, 14, 15):
             pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", variant))
             for stats in (True, False):
                 acc_g, st_g = gpuops.render(ctx, scene, cam, 3, 1, 7, stats=stats)
@@ -268,7 +268,7 @@ def test_production_traversal_kernel_ray_by_ray(pt, orc, ctx, name):
             o, dd = _mesh_rays(desc, cam, orc, obj, rng)
             ho = orc.trace(desc, o, dd, obj)
             assert (ho["object"] == obj).sum() > 1000
-            for variant in (0, 7, 9, 14, 15):
+            for variant in (0, 7, 9, 13, 14, 15):
                 pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", variant))
                 hg = gpuops.trace_queued(ctx, scene, o, dd, obj)
                 for k in ("object", "prim", "t_bits", "bary"):
@@ -305,7 +305,7 @@ def test_group_box_culling_under_grazing_rays(pt, orc, ctx, tmp_path):
                 o, dd, tgt = gs.grazing_rays(desc, 0, 150000, rng)
                 ho = orc.trace(desc, o, dd, 0)
                 assert ((ho["object"] == 0) & (ho["prim"] == tgt)).sum() > 10000   # the rays do reach the triangles aimed at
-            for variant in (0, 7, 9, 15):
+            for variant in (0, 7, 9, 13, 15):
                 pt.check(lib.ptx_ctx_tune(ctx, b"trav_variant", variant))
                 hg = gpuops.trace_queued(ctx, scene, o, dd, 0)
                 for k in ("object", "prim", "t_bits", "bary"):

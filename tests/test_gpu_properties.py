@@ -193,7 +193,7 @@ def test_fat_leaves_match_oracle(pt, orc, ctx, tmp_path):
     gpuops.render_init(ctx, cam)
     acc_o, st_o = orc.render(desc, cam, 0, 4, 6)
     try:
-        for variant in (0, 7, 9, 14, 15):
+        for variant in (0, 7, 9, 13, 14, 15):
             _tune(pt, ctx, b"trav_variant", variant)
             acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 4, 6, stats=True)
             assert np.array_equal(acc_o.view(np.uint32), acc_g.view(np.uint32)), f"variant {variant}"
@@ -254,7 +254,7 @@ def test_leaf_beyond_8192_triangles_matches_oracle(pt, orc, ctx, tmp_path):
     prims = ho["prim"][ho["hit"] == 1].astype(np.int64)
     assert prims.max() - prims.min() > 2 * 8192
     try:
-        for variant in (0, 7, 9, 14, 15):
+        for variant in (0, 7, 9, 13, 14, 15):
             _tune(pt, ctx, b"trav_variant", variant)
             hq = gpuops.trace_queued(ctx, scene, o, dd, 1)
             for k in ("object", "prim", "t_bits", "bary"):
@@ -426,7 +426,7 @@ def test_hand_built_deep_tree_uses_the_fallback_modes(pt, orc, ctx, D):
         hg = gpuops.trace(ctx, scene, o, d, 0)
         for k in ho:
             assert np.array_equal(ho[k], hg[k]), k
-        for variant in (0, 7, 9, 14, 15):
+        for variant in (0, 7, 9, 13, 14, 15):
             _tune(pt, ctx, b"trav_variant", variant)
             hq = gpuops.trace_queued(ctx, scene, o, d, 0)
             for k in ("object", "prim", "t_bits", "bary"):
