@@ -156,9 +156,9 @@ typedef struct PtxStats {
 	 *   x_unit_steps  steps of the unit phase (16 groups of eight triangles each), x_units the groups tested in them
 	 *   x_unit_phases rounds with a leaf phase (unified: unit phases), x_turns commit / refill turns
 	 * wide traversal (pt_wide.h, variant 14): x_iters = visit iterations, x_item_lanes = wide-node visits, x_half_lanes =
-	 *   rays handed to the exact kernel (diag3 of them for a full stack), x_wait_lanes = stacked children dropped at the pop,
+	 *   rays handed to the strict kernel (diag3 of them for a full stack), x_wait_lanes = stacked children dropped at the pop,
 	 *   x_unit_steps / x_units as above, x_unit_phases = drains; diag0..2 = clock ticks in turns / node visits / unit steps;
-	 *   lane_steps_active = rays handed to the exact kernel because their winning hit was not robust (pt_wide.h) */
+	 *   lane_steps_active = rays handed to the strict kernel because their winning hit was not robust (pt_wide.h) */
 	uint64_t x_iters, x_item_lanes, x_half_lanes, x_wait_lanes, x_unit_steps, x_units, x_unit_phases, x_turns;
 	/* shading divergence in the segment kernel, counting variant only (the material-sorting question):
 	 * waves in which at least one lane shades a hit, the lanes that do, the BSDF branches (diffuse / specular /
@@ -243,11 +243,14 @@ int ptx_wavefront_counts(PtxCtx* ctx, int max_bounces, int32_t* live_out, int32_
 int ptx_profile_enable(PtxCtx* ctx, int enable);
 int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches, float* segment_ms, int32_t* segment_launches);
 /* Scheduling knobs of the render path (no reference counterpart). key =
- *   "trav_variant"    traversal kernel: 0 (default) = the wide traversal (pt_wide.h) + the exact kernel over its retry queue,
- *                     14 = the same with the wide kernel's own counting twin, 15 = the EXACT kernel alone (the reference's
- *                     node-by-node visiting order, src/intersect.cuh:119-212)
+ *   "trav_variant"    traversal kernel: 0 (default) = the wide traversal (pt_wide.h) + the strict kernel over its retry queue,
+ *                     14 = the same with the wide kernel's own counting twin, 15 = the STRICT kernel alone: the reference's
+ *                     node-by-node visiting order (src/intersect.cuh:119-212) and every triangle of every visited leaf;
+ *                     7 / 9 = the strict kernel pinned to one of its two leaf loops (15 picks by tree depth), 13 = the
+ *                     GROUPED kernel: the reference's visiting order, but inside a leaf only the groups of eight triangles
+ *                     whose box the ray meets (the default until r2 mid-round; what the counting pass runs)
  *   "wide_margin_ppm" margin of the wide traversal's distance culling, parts per million (default 10000 = 1 %)
- *   "wide_scap"       stack entries per lane of the wide traversal (default 10; rays that need more go to the exact kernel)
+ *   "wide_scap"       stack entries per lane of the wide traversal (default 10; rays that need more go to the strict kernel)
  *   "wide_build"      which 4-wide tree a multi-node mesh gets at the NEXT ptx_scene_upload: 0 (default) the cheaper, by modelled
  *                     cost, of 1 = the tree collapsed from the reference's KD tree and 2 = one built by the surface-area heuristic
  *   "seg_mode"        1 (default) segment kernel with the bounce loop inside the launch (pt_segloop.h), 0 = one bounce per launch
@@ -260,11 +263,13 @@ int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches,
  *                     (the bounce-loop kernel would lose its fifth wave per SIMD to them), 2 for both
  *   "trav_blocks"     persistent workgroups per CU (the wide kernel launches at most six: what is resident);  "wf_batch"  samples per wavefront pass (1..256, default 128)
  *   "megakernel"      1 = one-lane-per-pixel kernel instead of the wavefront pipeline
- * WHAT CAN CHANGE A RESULT: nothing but "trav_variant" 0 / 14 together with "wide_margin_ppm", and only on rays at grazing
- * incidence where the reference's triangle test accepts a hit out of rounding noise (|det| ~ 1e-7 |e1||e2|) on a triangle
- * whose boxes lie more than the margin behind a well-conditioned hit: measured 1 ray in 2 000 000 adversarial grazing rays
- * on the headline mesh, 0 pixels of the headline frame at 1000 spp (tests/test_gpu_wide.py). "trav_variant"
- * 15 reproduces the reference on those too. Every other knob only reschedules work; the parity tests run the variants
+ * WHAT CAN CHANGE A RESULT: nothing but "trav_variant" 0 / 14 / 13 (with "wide_margin_ppm" and "grp_pad_ppm"), and only on
+ * rays at grazing incidence where the reference's triangle test accepts a hit out of rounding noise (|det| ~ 1e-7 |e1||e2|:
+ * a distance or barycentrics that float64 arithmetic contradicts) on a triangle whose group box the ray does not meet, or
+ * whose boxes lie more than the margin behind a well-conditioned hit: measured 7 rays in 19 654 555 adversarial grazing
+ * rays on the headline mesh (the same seven for 0 and 13; tests/golden/grazing_hard_rays.npz), 0 pixels of the headline
+ * frame at 1000 spp (tests/test_gpu_wide.py). "trav_variant" 15 / 7 / 9, ptx_trace_rays and the
+ * "megakernel" path reproduce the reference on those too. Every other knob only reschedules work; the parity tests run the variants
  * against each other. Defaults come from the environment (PTX_TRAV_VARIANT, PTX_WIDE_MARGIN_PPM, PTX_WIDE_SCAP,
  * PTX_WIDE_BUILD, PTX_SEG_MODE, PTX_SEG_BLOCKS, PTX_GRP_MODE, PTX_GRP_PAD_PPM, PTX_SEG_LDS_TABLES, PTX_TRAV_BLOCKS, PTX_WF_BATCH, PTX_MEGAKERNEL) at
  * ptx_ctx_create; value < 0 restores that default. */

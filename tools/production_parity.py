@@ -1,4 +1,4 @@
-"""Default traversal (variant 0) against the exact kernel alone (variant 15) on the PRODUCTION ray distribution: the
+"""Default traversal (variant 0) against the strict kernel alone (variant 15: every triangle of every leaf the reference visits) on the PRODUCTION ray distribution: the
 headline frame at S samples per pixel (default 1000 = 4.4e9 path segments); prints how many pixels of the float
 accumulation buffers differ. Usage (GPU box): python tools/production_parity.py [spp]"""
 import sys, os, importlib, time
@@ -21,4 +21,4 @@ for variant in (15, 0):
     print(f"variant {variant}: {st.rays} segments in {time.time() - t0:.2f} s", flush=True)
 pt.check(pt.lib().ptx_ctx_tune(ctx, b"trav_variant", -1))
 bad = (out[15].view(np.uint32) != out[0].view(np.uint32)).any(axis=1)
-print(f"{spp} spp: {int(bad.sum())} of {len(bad)} pixels differ between the default traversal and the exact kernel")
+print(f"{spp} spp: {int(bad.sum())} of {len(bad)} pixels differ between the default traversal and the strict kernel")
