@@ -1,6 +1,6 @@
 """How often the default traversal deviates from the oracle on ADVERSARIAL rays (tools/grazing_stress.py's generator: rays
 within a hair of triangle edges at incidences of 1e-6 ... 1e-1 rad), at a larger sample than the 2 000 000 of the fence test
-in tests/test_gpu_wide.py: ten independent sets of 2 000 000 on the headline mesh, default traversal and exact kernel.
+in tests/test_gpu_wide.py: ten independent sets of 2 000 000 on the headline mesh, default traversal (0) and strict kernel (15) by default; GRAZE_VARIANTS=0,13,15,9,7 compares more, GRAZE_SAVE=file.npz keeps the rays variant 0 differs on.
 Usage (GPU box): python tools/grazing_rate.py [sets] [rays per set]"""
 import sys, os, importlib
 import numpy as np
