@@ -394,7 +394,7 @@ def main():
     trav_formula = "68 B x traversals (queue entry, ray and current best in, closest hit out); tree and triangles are cache-resident"
 
     # The two kernel classes of a step (HIP event pairs around every launch; a traversal pair spans the wide kernel
-    # and the exact kernel's retry launch behind it). Since the wide traversal they take about the same time on the
+    # and the strict kernel's retry launch behind it). Since the wide traversal they take about the same time on the
     # headline scene, so the dominant one is whichever is larger in THIS run and the other is reported beside it.
     seg_name = "wf_segment_loop_kernel<0," if os.environ.get("PTX_SEG_MODE", "1") != "0" else "wf_segment_kernel<0,"
     trav = kernel_view("wf_traverse_wide_kernel<0,", trav_ms.value, trav_n.value, trav_bytes, trav_formula) if trav_n.value > 0 else None

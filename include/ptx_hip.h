@@ -245,7 +245,10 @@ int ptx_profile_get(PtxCtx* ctx, float* traverse_ms, int32_t* traverse_launches,
 /* Scheduling knobs of the render path (no reference counterpart). key =
  *   "trav_variant"    traversal kernel: 0 (default) = the wide traversal (pt_wide.h) + the strict kernel over its retry queue,
  *                     14 = the same with the wide kernel's own counting twin, 15 = the STRICT kernel alone: the reference's
- *                     node-by-node visiting order (src/intersect.cuh:119-212) and every triangle of every visited leaf;
+ *                     node-by-node visiting order (src/intersect.cuh:119-212) and every triangle of every visited leaf -
+ *                     and, in ptx_render_samples, segment kernels that test every triangle of the single-leaf meshes
+ *                     instead of culling them by pair boxes: the STRICT SCHEDULE, nothing is skipped on the strength of a
+ *                     box the reference does not have;
  *                     7 / 9 = the strict kernel pinned to one of its two leaf loops (15 picks by tree depth), 13 = the
  *                     GROUPED kernel: the reference's visiting order, but inside a leaf only the groups of eight triangles
  *                     whose box the ray meets (the default until r2 mid-round; what the counting pass runs)

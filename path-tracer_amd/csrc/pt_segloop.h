@@ -419,7 +419,7 @@ __global__ __launch_bounds__(PT_BLOCK, COMPACT ? 6 : WSL_OCC) void wf_segment_lo
 							if (tris_in_lds) { const int q = 3 * (run_off + rel); g0 = sh_tri[q]; g1 = sh_tri[q + 1]; g2 = sh_tri[q + 2]; }
 							else { const int q = 3 * (first + rel); g0 = sc.tri_geom[q]; g1 = sc.tri_geom[q + 1]; g2 = sc.tri_geom[q + 2]; }
 						};
-						bool hit = WF_CHEAP_PAIRS ? leaf_only_mesh_pairs<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt, fetch) : leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
+						bool hit = (WF_CHEAP_PAIRS && !(FLAGS & PT_F_ALLTRIS)) ? leaf_only_mesh_pairs<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt, fetch) : leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
 						if (hit && tri >= 0) {
 							const f3 p = ray.o + tmin * ray.d;
 							const float d = length3(p - ray.o);

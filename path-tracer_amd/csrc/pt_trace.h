@@ -13,7 +13,9 @@
 
 #define PT_TRI_EPSILON 0.00000005f   // reference: src/intersect.cuh:10
 
-enum { PT_F_STATS = 1, PT_F_DEBUGMASK = 2 };
+// PT_F_ALLTRIS (segment kernels): single-leaf meshes by the reference's loop over EVERY triangle of the leaf instead of through
+// their pair boxes (pt_wavefront.h) - what trav_variant 15 / 7 / 9, the strict schedule, asks for
+enum { PT_F_STATS = 1, PT_F_DEBUGMASK = 2, PT_F_ALLTRIS = 4 };
 
 struct Ray {
 	f3 o, d, inv;

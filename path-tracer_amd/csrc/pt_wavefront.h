@@ -52,7 +52,7 @@ struct WfParams {
 	const float4* i0; const float4* i1; const float4* i2; const float4* i3;   // state set of the previous bounce (read)
 	Rad3* rad;                // [batch][npix], 12 B each: a finished path parks its radiance here
 	int* queue[PT_MAX_BIG];   // per multi-node mesh: slots (in s0..s3) of the paths whose ray enters its root box
-	int* retry;               // slots of the rays the wide traversal (pt_wide.h) hands to the exact kernel; shared by the queues in turn
+	int* retry;               // slots of the rays the wide traversal (pt_wide.h) hands to the strict kernel; shared by the queues in turn
 	int use_retry;            // wf_traverse_coop_kernel: take the rays from `retry` instead of queue[slot]
 	int* counters;            // [bounce][1 + PT_MAX_BIG]: live count, queue counts (zeroed per batch)
 	PtxStats* stats;
@@ -207,8 +207,11 @@ PT_DEV bool leaf_only_mesh(const DevScene& sc, const DevObject& ob, const Ray& r
 // The same mesh through its PAIR boxes (pt_scene.h, cheap_pairs): every lane first tests the boxes of all pairs of
 // consecutive triangles (wave-uniform data: scalar loads, one slab test each) and then only the pairs its ray touches
 // (its own loads from tri_geom), in run order with strict '<' - what the serial loop above keeps, because a pair
-// whose padded box the ray misses holds no hit (the argument of the group boxes). A ray inside the
-// sky cube tests one face instead of twelve triangles; the loop below runs once for most waves.
+// whose padded box the ray misses holds no hit - up to the SAME exception as the group boxes: at
+// grazing incidence the reference's test can accept a triangle the ray passes beside, box and all, out of rounding noise.
+// Never observed on a pair box (every comparison with the oracle, 105 M segments of the full frame among them, is
+// identical), but the strict schedule (PT_F_ALLTRIS) takes the serial loop above to be strict by construction. A ray inside
+// the sky cube tests one face instead of twelve triangles; the loop below runs once for most waves.
 // `fetch(first, rel, g0, g1, g2)`: the three words of triangle first + rel of tri_geom - from global memory, or from a
 // copy of the single-leaf meshes' runs in LDS (pt_segloop.h): the loop below is a chain of dependent loads.
 struct GlobalTriFetch {
@@ -227,8 +230,13 @@ PT_DEV bool leaf_only_mesh_pairs(const DevScene& sc, const DevObject& ob, const 
 	const int pair_base = __builtin_amdgcn_readfirstlane(__float_as_int(q0.y));
 	if (FLAGS & PT_F_STATS) { cnt.n_leaf++; cnt.n_tri += (uint32_t)count; }   // the reference's count: every triangle of the leaf
 	const int npairs = (count + 1) >> 1;
-	// slab test as fma(plane, inv, -o * inv); a NaN (0 * inf, inf - inf) drops out of min / max: that axis does not constrain
-	const float nx = -ray.o.x * ray.inv.x, ny = -ray.o.y * ray.inv.y, nz = -ray.o.z * ray.inv.z;
+	// slab test as (plane - o) * inv, the IEEE form: with a direction component of exactly zero (inv = inf; a camera ray
+	// of the centre column, say) the two planes give -inf and +inf when the origin lies between them, and a NaN (0 * inf:
+	// the origin ON a padded plane) drops out of min / max. Until late round 3 this was fma(plane, inv, -o * inv), one
+	// instruction less per plane - and wrong for such rays: plane * inf - o * inf is inf - inf = NaN for the plane on the
+	// origin's side of zero, the NaN dropped out, both bounds of the axis became the other plane's -inf and the box was
+	// "missed": one black pixel in every ten samples of the headline frame (tools/strict_diff.py found it).
+	// The difference form also keeps the rounding relative to the distance from the box instead of from the scene's origin.
 	bool intersects = false;
 	for (int base = 0; base < npairs; base += 32) {
 		const int nb = npairs - base < 32 ? npairs - base : 32;
@@ -236,9 +244,9 @@ PT_DEV bool leaf_only_mesh_pairs(const DevScene& sc, const DevObject& ob, const 
 		for (int j = 0; j < nb; ++j) {
 			const float4* pr = sc.cheap_pairs + 2 * (size_t)(pair_base + base + j);
 			const float4 lo = pr[0], hi = pr[1];
-			const float ax = __builtin_fmaf(lo.x, ray.inv.x, nx), bx = __builtin_fmaf(hi.x, ray.inv.x, nx);
-			const float ay = __builtin_fmaf(lo.y, ray.inv.y, ny), by = __builtin_fmaf(hi.y, ray.inv.y, ny);
-			const float az = __builtin_fmaf(lo.z, ray.inv.z, nz), bz = __builtin_fmaf(hi.z, ray.inv.z, nz);
+			const float ax = (lo.x - ray.o.x) * ray.inv.x, bx = (hi.x - ray.o.x) * ray.inv.x;
+			const float ay = (lo.y - ray.o.y) * ray.inv.y, by = (hi.y - ray.o.y) * ray.inv.y;
+			const float az = (lo.z - ray.o.z) * ray.inv.z, bz = (hi.z - ray.o.z) * ray.inv.z;
 			const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
 			const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
 			if (!(tn > tf) && !(tf < 0.0f)) touched |= 1u << j;
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(PT_BLOCK, WF_SEG_OCC) void wf_segment_kernel(DevSce
 				} else if (enter) {
 					float tmin = __builtin_huge_valf(), bu = 0.0f, bv = 0.0f;
 					int tri = -1;
-					bool hit = WF_CHEAP_PAIRS ? leaf_only_mesh_pairs<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt) : leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
+					bool hit = (WF_CHEAP_PAIRS && !(FLAGS & PT_F_ALLTRIS)) ? leaf_only_mesh_pairs<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt) : leaf_only_mesh<FLAGS>(sc, ob, ray, tmin, tri, bu, bv, cnt);
 					if (hit && tri >= 0) {
 						const f3 p = ray.o + tmin * ray.d;
 						const float d = length3(p - ray.o);

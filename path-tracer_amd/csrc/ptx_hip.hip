@@ -315,7 +315,7 @@ static void free_scene_allocs(PtxScene* s) {
 // Four boxes in 48 bytes (pt_scene.h, grp_qbox / wide nodes): the union U of the used boxes as origin and
 // step = extent / 255 per axis, then per box six bytes (lo.xyz rounded down, hi.xyz rounded up, in steps from U's
 // origin). The decoded box always contains the given one; an unused slot is (255, 255, 255, 0, 0, 0): never touched.
-// Byte order: box-major (box g = bytes 6g .. 6g+5: lo.xyz, hi.xyz; the exact kernel's grp_qbox) or, for the wide nodes,
+// Byte order: box-major (box g = bytes 6g .. 6g+5: lo.xyz, hi.xyz; the grouped kernel's grp_qbox) or, for the wide nodes,
 // AXIS-major (word 2k = the four lo codes of axis k, word 2k+1 the four hi codes, box g in byte g): a ray then picks its
 // near and far faces per axis by swapping two words on the sign of its direction, once per node instead of once per box.
 static void quantise_boxes4(const float lo[4][3], const float hi[4][3], const bool used[4], float4 out[3], bool axis_major = false) {
@@ -985,7 +985,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 			cand_cost[which] = wb.cost;
 		}
 		int use = cand_root[0] < 0 ? 1 : (cand_root[1] < 0 ? 0 : (cand_cost[1] < 0.9 * cand_cost[0] ? 1 : 0));
-		// rays that need more stack entries than a lane has (WFW_SCAP_MAX) go to the exact kernel: rare on either tree of the test
+		// rays that need more stack entries than a lane has (WFW_SCAP_MAX) go to the strict kernel: rare on either tree of the test
 		// meshes (0 and 1400 of 10^8 traversals), but a degenerate chain would send most rays there: then prefer the tree that fits
 		if (cand_root[0] >= 0 && cand_root[1] >= 0 && cand_stack[use] > 3 * WFW_SCAP_MAX && cand_stack[use ^ 1] <= 3 * WFW_SCAP_MAX) use ^= 1;
 		if (getenv("PTX_WIDE_BUILD_VERBOSE"))
@@ -1191,6 +1191,8 @@ static int check_scene(const PtxCtx* ctx, const PtxScene* scene, const char* who
 //                             of every leaf it visits (leaf mode 4, or 3 when the tree's stack leaves no LDS for 4's staging area):
 //                             the reference's test set, so also the hits its triangle test accepts out of rounding noise
 //                7, 9         the strict kernel in leaf mode 3 / 4 by name (so that both are tested on ordinary scenes)
+//                             (15, 7 and 9 are the STRICT SCHEDULE: ptx_render_samples then also runs the segment kernels that test every
+//                             triangle of the single-leaf meshes instead of culling by their pair boxes, PT_F_ALLTRIS)
 //                13           the reference's visiting order with GROUPED leaves (leaf mode 9: a leaf's triangles in groups of eight
 //                             with a padded box each, only touched groups tested): 1.75 x as fast as 15, and like the wide
 //                             traversal blind to a noise hit on a triangle whose group box the ray misses (7 of 19.7 million
@@ -1213,7 +1215,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 #define WIDE(F) hipLaunchKernelGGL((wf_traverse_wide_kernel<F, 6, WFW_CHUNK, WFW_TURN_MIN, WFW_DRAIN_MIN>), dim3((unsigned)tbw), dim3(PT_BLOCK), wide_lds, ctx->stream, scene->dev, wp, obj, k, scap, 1.0f + 1e-6f * (float)ctx->wide_margin_ppm, 1e-6f * (float)ctx->wide_margin_ppm)
 	const bool stage_fits = lds + WF_STAGE_BYTES <= 64 * 1024;
 	const bool grp_fits = lds + WF_GRP_BYTES <= 64 * 1024;
-	// the exact kernel in the best leaf mode the tree's stack leaves LDS for (or the one a test asks for)
+	// the reference-order kernel: strict in the best leaf loop the tree's stack leaves LDS for, or the leaf mode asked for by name
 	auto exact = [&](const WfParams& wp, size_t tb, bool stats) {
 		// strict (4, else 3) unless the grouped kernel is asked for by name, or counters are collected (same counters, faster)
 		const int mode = ctx->trav_variant == 7 ? 3 : ctx->trav_variant == 9 ? 4 : (ctx->trav_variant == 13 || stats) ? 9 : 4;
@@ -1237,7 +1239,7 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 	const bool wide = ctx->trav_variant == 0 || ctx->trav_variant == 14;
 	if (collect_stats) {
 		if (ctx->trav_variant == 14) { WIDE(PT_F_STATS); exact_retry(); }
-		else exact(wp, tb, true);   // the reference's counters: the exact kernel's counting twin
+		else exact(wp, tb, true);   // the reference's counters: the grouped reference-order kernel's counting twin
 	} else if (wide) { WIDE(0); exact_retry(); }
 	else exact(wp, tb, false);
 #undef WIDE
@@ -1326,6 +1328,8 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 			if (seg_loop && blocks > (size_t)cus * (size_t)ctx->seg_blocks_per_cu) blocks = (size_t)cus * (size_t)ctx->seg_blocks_per_cu;
 			// material / texture-descriptor tables in LDS: the per-bounce kernel gains 2.5 % from them; the bounce-loop kernel loses its fifth
 			// wave per SIMD to them (39.4 KB per workgroup instead of 30.7: 6.58 vs 5.70 ms per launch), so there they need seg_lds_tables = 2
+			// the strict schedule (trav_variant 15 / 7 / 9): no triangle is skipped on the strength of a box that is not the reference's own
+			const bool strict = ctx->trav_variant == 15 || ctx->trav_variant == 7 || ctx->trav_variant == 9;
 			const bool lds_tables = (seg_loop ? ctx->seg_lds_tables >= 2 : ctx->seg_lds_tables >= 1) && scene->dev.num_materials <= WF_LDS_MATS && scene->dev.num_textures <= WF_LDS_TEXS;
 			// the set this bounce's new rays are written to (and its traversals update): set `bounce` of the bounce-loop kernel,
 			// else the two sets in turn
@@ -1341,6 +1345,8 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				                     scene->dev.num_tris <= WSL_COMPACT_MAX_TRIS && dyn <= 256;
 				if (collect_stats)
 					hipLaunchKernelGGL((wf_segment_loop_kernel<PT_F_STATS, 0, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
+				else if (strict)   // every triangle of the single-leaf meshes too (PT_F_ALLTRIS)
+					hipLaunchKernelGGL((wf_segment_loop_kernel<PT_F_ALLTRIS, 0, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
 				else if (lds_tables)
 					hipLaunchKernelGGL((wf_segment_loop_kernel<0, 1, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), dyn, ctx->stream, scene->dev, ctx->cam, wp);
 				else if (compact)
@@ -1353,6 +1359,8 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				wp.i0 = ctx->wf.s0 + in_set * stride; wp.i1 = ctx->wf.s1 + in_set * stride; wp.i2 = ctx->wf.s2 + in_set * stride; wp.i3 = ctx->wf.s3 + in_set * stride;
 				if (collect_stats)
 					hipLaunchKernelGGL((wf_segment_kernel<PT_F_STATS, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
+				else if (strict)
+					hipLaunchKernelGGL((wf_segment_kernel<PT_F_ALLTRIS, 0>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
 				else if (lds_tables)   // material / texture-descriptor tables in LDS when they fit (pt_wavefront.h)
 					hipLaunchKernelGGL((wf_segment_kernel<0, 1>), dim3((unsigned)blocks), dim3(PT_BLOCK), 0, ctx->stream, scene->dev, ctx->cam, wp);
 				else

@@ -314,3 +314,50 @@ def test_group_box_culling_under_grazing_rays(pt, orc, ctx, tmp_path):
     finally:
         pt.check(lib.ptx_ctx_tune(ctx, b"grp_pad_ppm", -1))
         pt.check(lib.ptx_ctx_tune(ctx, b"trav_variant", -1))
+
+
+_BOX_FACES = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+
+
+@pytest.mark.parametrize("direction,up,zero_axis", [((0, 0, -1), (0, 1, 0), 0), ((0, 0, -1), (1, 0, 0), 1), ((-1, 0, 0), (0, 1, 0), 2)])
+def test_rays_with_a_zero_direction_component_through_single_leaf_meshes(pt, orc, ctx, tmp_path, direction, up, zero_axis):
+    """A camera whose centre column looks exactly along a coordinate plane (65 x 64 pixels of 1/32: the column's offset
+    is 0 in floating point; no jitter): those rays have a direction component of exactly 0, an infinite inverse, and
+    every box test on their way must treat the axis as 'inside or outside for good'. The single-leaf meshes (a closed
+    luminous box around everything, a floor) are culled by pair boxes in the segment kernels; until late round 3 that
+    test formed plane * inf - o * inf = NaN and let such rays through the whole box: one black pixel in ten samples of
+    the headline frame (tools/strict_diff.py). Every schedule must equal the oracle, pixel by pixel."""
+    c = np.array([[x, y, z] for x in (-40.0, 47.0) for y in (-3.0, 51.0) for z in (-44.0, 39.0)])
+    lines = ["mtllib m.mtl", "usemtl sky.lumi"] + ["v %.9g %.9g %.9g" % tuple(q) for q in c]
+    for f in _BOX_FACES:
+        lines += ["f %d %d %d" % (f[0] + 1, f[1] + 1, f[2] + 1), "f %d %d %d" % (f[0] + 1, f[2] + 1, f[3] + 1)]
+    (tmp_path / "box.obj").write_text("\n".join(lines) + "\n")
+    (tmp_path / "floor.obj").write_text("mtllib m.mtl\nusemtl ground.diff\nv -20 0 -20\nv 20 0 -20\nv 20 0 20\nv -20 0 20\nf 1 3 2\nf 1 4 3\n")
+    (tmp_path / "m.mtl").write_text("newmtl sky.lumi\nKd 1 1 1\nKe 0.9 0.8 0.7\nnewmtl ground.diff\nKd 0.7 0.6 0.5\n")
+    pos = [3.25, 2.5, 5.75]
+    (tmp_path / "s.json").write_text(
+        '{"camera": {"pixelWidth": 65, "pixelHeight": 64, "direction": [%d,%d,%d], "up": [%d,%d,%d], "position": [%g,%g,%g],'
+        ' "screenDist": 1.5, "screenHeight": 2}, "objects": ['
+        '{"type": "sphere", "render": true, "radius": 1.0, "position": [0, 1, 0], "material": {"type": "spec", "Kd": [0.9], "Ns": [900], "d": [0.2]}},'
+        '{"type": "mesh", "render": true, "src": "%s"}, {"type": "mesh", "render": true, "src": "%s"}]}'
+        % (*direction, *up, *pos, tmp_path / "box.obj", tmp_path / "floor.obj"))
+    desc, cam = pt.load_scene(str(tmp_path / "s.json"))
+    cam.aa_jitter = 0.0
+    scene = pt.host().pth_scene_device()
+    o, d = orc.generate_rays(cam, 0, 0)
+    col = d.reshape(64, 65, 3)[:, 32, :]
+    assert (col[:, zero_axis] == 0.0).all(), "the centre column's rays are meant to have an exactly zero component"
+    gpuops.render_init(ctx, cam)
+    acc_o, st_o = orc.render(desc, cam, 0, 8, 3)
+    assert (acc_o[:, :3].sum(axis=1) > 0).all(), "closed luminous box: no path of the oracle ends in the dark"
+    try:
+        for key, val in ((b"trav_variant", 0), (b"trav_variant", 15), (b"seg_mode", 0), (b"seg_compact", 0), (b"megakernel", 1)):
+            pt.check(pt.lib().ptx_ctx_tune(ctx, key, val))
+            acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 8, 3)
+            pt.check(pt.lib().ptx_ctx_tune(ctx, key, -1))
+            bad = np.nonzero((acc_o.view(np.uint32) != acc_g.view(np.uint32)).any(axis=1))[0]
+            assert len(bad) == 0, f"{key.decode()}={val}: {len(bad)} pixels differ, first {bad[:5]} (x = {bad[:5] % 65})"
+            assert st_o.rays == st_g.rays
+    finally:
+        for key in (b"trav_variant", b"seg_mode", b"seg_compact", b"megakernel"):
+            pt.check(pt.lib().ptx_ctx_tune(ctx, key, -1))

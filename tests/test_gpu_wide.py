@@ -1,9 +1,9 @@
-"""The wide traversal (csrc/pt_wide.h, the default since round 2) and its exits to the exact kernel.
+"""The wide traversal (csrc/pt_wide.h, the default since round 2) and its exits to the strict kernel.
 
 The wide kernel walks its own 4-wide tree and returns the minimum t over all triangles; which of two triangles
-with the SAME t wins is the reference's visiting order, which only the exact kernel (leaf mode 9) knows. Rays
+with the SAME t wins is the reference's visiting order, which only the reference-order kernel (wf_traverse_coop_kernel; strict leaf loops on the retry queue) knows. Rays
 in that situation, and rays whose stack is full, go through the retry queue. These tests force both exits and
-compare with the oracle / the exact kernel bit for bit; the counters of the wide kernel's own counting twin
+compare with the oracle / the strict kernel bit for bit; the counters of the wide kernel's own counting twin
 (variant 14) prove that the exits were taken. All through the C ABI."""
 import ctypes as C
 
@@ -21,7 +21,7 @@ def _tune(pt, ctx, key, value):
 
 def test_equal_t_from_two_blocks_goes_to_the_exact_kernel(pt, orc, ctx, tmp_path):
     """100 identical triangles form one leaf of four 32-slot blocks: every hit has the same t in all of them, the
-    wide kernel cannot know which the reference tests first, and the exact kernel must decide (the first)."""
+    wide kernel cannot know which the reference tests first, and the strict kernel must decide (the first)."""
     # ONE mesh: a bumpy floor that makes the builder split, and 100 copies of one triangle above it (equal centroids:
     # they stay together in a leaf that spans several blocks)
     g = 12
@@ -96,7 +96,7 @@ def test_full_stack_goes_to_the_exact_kernel(pt, orc, ctx, scap):
 
 
 def test_wide_and_exact_kernels_agree_on_every_scene(pt, ctx):
-    """Variant 0 (wide + retry), 14 (the same with its own counting twin) and 15 (the exact kernel alone) give the
+    """Variant 0 (wide + retry), 14 (the same with its own counting twin) and 15 (the strict kernel alone) give the
     same accumulation buffer on every shipped scene with a multi-node mesh; the default stack never overflows on
     the car."""
     for name in ("lamborghini", "teapot"):
@@ -123,7 +123,7 @@ def test_fragile_hits_at_grazing_incidence_equal_the_oracle(pt, orc, ctx):
     in front of its own boxes and beats a well-conditioned hit behind which its box lies. 400 000 grazing rays on the
     car (tools/grazing_stress.py, the set on which the first wide kernel differed from the oracle in rays 104296,
     134791 and 302464): with the culling margin and the robust-hit check every ray equals the oracle, through the
-    wide kernel, its counting twin's kernel and the exact kernel alone."""
+    wide kernel, its counting twin's kernel and the strict kernel alone."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("grazing_stress", os.path.join(os.path.dirname(__file__), "..", "tools", "grazing_stress.py"))
     gs = importlib.util.module_from_spec(spec)
@@ -295,7 +295,7 @@ def test_unevenly_tessellated_mesh_matches_the_oracle(pt, orc, ctx, tmp_path, gr
     """The headline stand-in is evenly tessellated. tools/uneven_mesh.py is its opposite: panels with edges of 2-4 units, 300
     slivers of 4 x 0.006, 40 blobs with edges of ~0.02 (100:1 in edge length, 10^4:1 in area), 1500 needles of aspect 100:1;
     diffuse, glossy and glass materials. Render and ray-by-ray hits equal the oracle through the default traversal, its
-    counting twin and the exact kernel, for both ways of cutting leaves into groups (grp_mode: bisection / strips) and for both
+    counting twin and the strict kernel, for both ways of cutting leaves into groups (grp_mode: bisection / strips) and for both
     candidates of the wide tree (wide_build 1 = collapsed from the reference's KD tree, 2 = surface-area heuristic; 0 = the
     library's choice, which on this mesh is the latter: 32 instead of 58 node visits per traversal)."""
     import importlib.util, os
