@@ -286,8 +286,18 @@ def test_production_rays_default_and_exact_traversal_accumulate_identically(pt, 
         assert st_e.rays == st_w.rays > 1.0e9
         bad = np.nonzero((ref.view(np.uint32) != acc.view(np.uint32)).any(axis=1))[0]
         assert len(bad) == 0, f"{len(bad)} pixels differ, first {bad[:5]}"
+        # and the one-lane-per-pixel megakernel (the reference's loops as written: no wide tree, no group or pair boxes, no
+        # LDS pool), which shares no culling structure with either: the pair-box bug of rounds 2-3 showed
+        # as 16 missing segments here
+        _tune(pt, ctx, b"trav_variant", -1)
+        _tune(pt, ctx, b"megakernel", 1)
+        mk, st_m = gpuops.render(ctx, scene, cam, 0, 256, 7, batch=128)
+        assert st_m.rays == st_w.rays
+        bad = np.nonzero((mk.view(np.uint32) != acc.view(np.uint32)).any(axis=1))[0]
+        assert len(bad) == 0, f"megakernel: {len(bad)} pixels differ, first {bad[:5]}"
     finally:
         _tune(pt, ctx, b"trav_variant", -1)
+        _tune(pt, ctx, b"megakernel", -1)
 
 
 @pytest.mark.parametrize("grp_mode,wide_build", [(1, 0), (0, 0), (1, 1), (1, 2)])
