@@ -335,13 +335,29 @@ def test_rays_with_a_zero_direction_component_through_single_leaf_meshes(pt, orc
     (tmp_path / "floor.obj").write_text("mtllib m.mtl\nusemtl ground.diff\nv -20 0 -20\nv 20 0 -20\nv 20 0 20\nv -20 0 20\nf 1 3 2\nf 1 4 3\n")
     (tmp_path / "m.mtl").write_text("newmtl sky.lumi\nKd 1 1 1\nKe 0.9 0.8 0.7\nnewmtl ground.diff\nKd 0.7 0.6 0.5\n")
     pos = [3.25, 2.5, 5.75]
+    # a tessellated ball in front of the camera (3120 triangles: a multi-node mesh, so the column's rays also walk the wide
+    # tree and the strict kernel with an infinite inverse), centred ON the camera axis
+    centre = np.array(pos) + 8.0 * np.array(direction, float)
+    nu, nv = 40, 40
+    th, ph = np.meshgrid(np.linspace(0.0, np.pi, nv + 1), np.linspace(0.0, 2.0 * np.pi, nu + 1), indexing="ij")
+    pts = centre + 2.5 * np.stack([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)], axis=-1)
+    lines = ["v %.9g %.9g %.9g" % tuple(q) for q in pts.reshape(-1, 3)]
+    idx = lambda i, j: i * (nu + 1) + j + 1
+    for i in range(nv):
+        for j in range(nu):
+            if i > 0:
+                lines.append("f %d %d %d" % (idx(i, j), idx(i, j + 1), idx(i + 1, j)))   # outward normals
+            if i < nv - 1:
+                lines.append("f %d %d %d" % (idx(i, j + 1), idx(i + 1, j + 1), idx(i + 1, j)))
+    (tmp_path / "ball.obj").write_text("\n".join(lines) + "\n")
     (tmp_path / "s.json").write_text(
         '{"camera": {"pixelWidth": 65, "pixelHeight": 64, "direction": [%d,%d,%d], "up": [%d,%d,%d], "position": [%g,%g,%g],'
         ' "screenDist": 1.5, "screenHeight": 2}, "objects": ['
         '{"type": "sphere", "render": true, "radius": 1.0, "position": [0, 1, 0], "material": {"type": "spec", "Kd": [0.9], "Ns": [900], "d": [0.2]}},'
-        '{"type": "mesh", "render": true, "src": "%s"}, {"type": "mesh", "render": true, "src": "%s"}]}'
-        % (*direction, *up, *pos, tmp_path / "box.obj", tmp_path / "floor.obj"))
+        '{"type": "mesh", "render": true, "src": "%s"}, {"type": "mesh", "render": true, "src": "%s"}, {"type": "mesh", "render": true, "src": "%s"}]}'
+        % (*direction, *up, *pos, tmp_path / "box.obj", tmp_path / "floor.obj", tmp_path / "ball.obj"))
     desc, cam = pt.load_scene(str(tmp_path / "s.json"))
+    assert desc.contents.num_nodes > 10, "the ball is meant to be a multi-node mesh"
     cam.aa_jitter = 0.0
     scene = pt.host().pth_scene_device()
     o, d = orc.generate_rays(cam, 0, 0)
@@ -349,9 +365,9 @@ def test_rays_with_a_zero_direction_component_through_single_leaf_meshes(pt, orc
     assert (col[:, zero_axis] == 0.0).all(), "the centre column's rays are meant to have an exactly zero component"
     gpuops.render_init(ctx, cam)
     acc_o, st_o = orc.render(desc, cam, 0, 8, 3)
-    assert (acc_o[:, :3].sum(axis=1) > 0).all(), "closed luminous box: no path of the oracle ends in the dark"
+    assert (acc_o[:, :3].sum(axis=1) > 0).mean() > 0.98, "closed luminous box: hardly a pixel of the oracle stays dark"
     try:
-        for key, val in ((b"trav_variant", 0), (b"trav_variant", 15), (b"seg_mode", 0), (b"seg_compact", 0), (b"megakernel", 1)):
+        for key, val in ((b"trav_variant", 0), (b"trav_variant", 15), (b"trav_variant", 13), (b"seg_mode", 0), (b"seg_compact", 0), (b"megakernel", 1)):
             pt.check(pt.lib().ptx_ctx_tune(ctx, key, val))
             acc_g, st_g = gpuops.render(ctx, scene, cam, 0, 8, 3)
             pt.check(pt.lib().ptx_ctx_tune(ctx, key, -1))
