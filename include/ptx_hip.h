@@ -223,6 +223,16 @@ int ptx_accum_clear(PtxCtx* ctx);
  * buffer. Asynchronous on the context's stream. `collect_stats` != 0 runs the counting variant. */
 int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
                        uint64_t seed, int collect_stats);
+/* reference: ONE call of kernelMain (src/kernel.cu:59-91) in the render thread's loop (qt/cudarunthread.cpp:21-41): adds
+ * exactly global sample `sample` to the accumulation buffer, bit for bit what ptx_render_samples(ctx, scene, sample, 1, seed, 0)
+ * adds. A one-sample pass cannot fill an MI355X (2.3 ms per sample of the headline frame, against 0.5 ms in a long pass), so
+ * the call TRACES AHEAD: a sample outside the window it holds is traced together with the w - 1 that follow it, their radiance
+ * stays parked per sample, and the calls for those samples only add their plane. w is 1 at first and doubles while the calls
+ * continue the window (up to max_ahead, at most the pass size "wf_batch"; max_ahead <= 1: no look-ahead). A window ends with
+ * anything that changes what a sample is or reuses the pass buffers: ptx_render_set_camera / _init / _cleanup,
+ * ptx_render_samples, ptx_ctx_tune, ptx_scene_free. Rays traced ahead are counted (ptx_stats_get) when they are traced.
+ * Memory: the path state of a pass of max_ahead samples. Asynchronous on the context's stream. */
+int ptx_render_sample_ahead(PtxCtx* ctx, const PtxScene* scene, int sample, uint64_t seed, int max_ahead);
 int ptx_render_sync(PtxCtx* ctx);
 /* accumulation buffer access (headless replacement for the mapped PBO, src/kernel.h:6-8) */
 void* ptx_accum_device_ptr(PtxCtx* ctx);

@@ -100,7 +100,7 @@ PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_device_info", "ptx_ctx_create", "ptx_ctx_destroy",
     "ptx_scene_upload", "ptx_scene_free", "ptx_scene_device_bytes", "ptx_scene_wide_sah_objects", "ptx_render_init", "ptx_render_set_camera",
     "ptx_render_cleanup", "ptx_accum_clear", "ptx_render_samples", "ptx_render_sync", "ptx_accum_device_ptr",
-    "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_stats_get", "ptx_stats_reset",
+    "ptx_render_sample_ahead", "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_stats_get", "ptx_stats_reset",
     "ptx_wavefront_counts", "ptx_ctx_tune", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_trace_rays_queued", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample", "ptx_selftest_rcp", "ptx_selftest_vec3",
 ]
 
@@ -136,6 +136,7 @@ def lib():
         L.ptx_render_cleanup.argtypes = [vp]
         L.ptx_accum_clear.argtypes = [vp]
         L.ptx_render_samples.argtypes = [vp, vp, i32, i32, u64, i32]
+        L.ptx_render_sample_ahead.argtypes = [vp, vp, i32, u64, i32]
         L.ptx_render_sync.argtypes = [vp]
         L.ptx_accum_device_ptr.argtypes = [vp]
         L.ptx_accum_device_ptr.restype = vp
@@ -171,6 +172,8 @@ def host():
         H.pth_last_error.restype = C.c_char_p
         H.pth_set_asset_root.argtypes = [C.c_char_p]
         H.pth_set_seed.argtypes = [C.c_uint64]
+        H.pth_set_look_ahead.argtypes = [i32]
+        H.pth_look_ahead.restype = i32
         H.pth_checkpoint_save.argtypes = [C.c_char_p, C.c_int32]
         H.pth_checkpoint_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32)]
         H.pth_autosave_due.argtypes = [C.c_int32, C.c_int32]

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(PT_BLOCK, COMPACT ? 6 : WSL_OCC) void wf_segment_lo
 	__shared__ float4 sh_mats[LDSTAB ? 3 * WF_LDS_MATS : 1];
 	__shared__ DevTexture sh_texs[LDSTAB ? WF_LDS_TEXS : 1];
 	__shared__ float sh_w[WORDS][CAP];
-	__shared__ int sh_live, sh_pool, sh_fresh_base, sh_fresh_n;
+	__shared__ int sh_live, sh_pool, sh_fresh_base, sh_fresh_n, sh_fresh_want;
 	extern __shared__ int sh_lists[];   // [nl_total][WSL_LIST_INTS]
 	if (LDSTAB) {
 		for (int i = tid; i < 3 * sc.num_materials; i += PT_BLOCK) sh_mats[i] = sc.materials[i];
@@ -149,17 +149,30 @@ __global__ __launch_bounds__(PT_BLOCK, COMPACT ? 6 : WSL_OCC) void wf_segment_lo
 		sh_cam[20] = cam.up[0]; sh_cam[21] = cam.up[1]; sh_cam[22] = cam.up[2]; sh_cam[23] = 0.0f;
 	}
 #endif
-	__shared__ int sh_pool_cur;
-	if (tid == 0) { sh_pool = 0; sh_live = 0; }
+	__shared__ int sh_pool_cur, sh_fresh_cap;
+	if (tid == 0) {
+		sh_pool = 0; sh_live = 0;
+		// SHORT INPUTS (the reference's own loop renders one sample per call, runCUDA: a launch then holds fewer entries than the
+		// grid has room for): a claim is no larger than the input's share of one workgroup, in whole wave-widths, so that the
+		// input spreads over the chip instead of filling a third of the workgroups. Long inputs keep CAP. Schedule only.
+		const int wgs = (int)gridDim.x;
+		int cap = CAP;
+		if (n_in < wgs * CAP) {
+			cap = (((n_in + wgs - 1) / wgs) + 63) & ~63;
+			cap = cap < 64 ? 64 : cap > CAP ? CAP : cap;
+		}
+		sh_fresh_cap = cap;
+	}
 	bool exhausted = n_in <= 0;   // block-uniform: the input has no entry left to claim
 	for (;;) {
 		const unsigned long long k0 = WSL_CLOCK();
 		__syncthreads();   // pool entries and counters of the previous iteration are complete, its reads of sh_live done
 		if (tid == 0) {
 			const int np = sh_pool;
-			int fb = 0, fn = 0;
+			int fb = 0, fn = 0, want = 0;
 			if (!exhausted && np < CAP) {
-				const int want = CAP - np;
+				want = CAP - np;
+				want = want < sh_fresh_cap ? want : sh_fresh_cap;
 				fb = atomicAdd(&WF_SCUR(wp, launch_bounce), want);
 				fn = n_in - fb;
 				fn = fn < 0 ? 0 : (fn > want ? want : fn);
@@ -167,13 +180,14 @@ __global__ __launch_bounds__(PT_BLOCK, COMPACT ? 6 : WSL_OCC) void wf_segment_lo
 			sh_pool_cur = np;
 			sh_fresh_base = fb;
 			sh_fresh_n = fn;
+			sh_fresh_want = want;
 			sh_pool = 0;
 			sh_live = 0;
 		}
 		for (int i = tid; i < nl_total * WSL_LIST_INTS; i += PT_BLOCK) sh_lists[i] = 0;
 		__syncthreads();
 		const int n_pool = sh_pool_cur, fresh_base = sh_fresh_base, n_fresh = sh_fresh_n;
-		if (n_fresh < CAP - n_pool) exhausted = true;   // the cursor ran past the end of the input
+		if (n_fresh < sh_fresh_want) exhausted = true;   // the cursor ran past the end of the input
 		if (n_pool + n_fresh == 0) break;
 
 		// ---- phase 1: shade pooled hits and fresh input, generate primary rays; compact the new rays (stage A) ----

@@ -86,6 +86,19 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 	feed.exhausted = false;
 	feed.next = feed.hi = 0;
 	int* cursor = &WF_CUR(wp, wp.bounce, 1 + slot_index);
+	// SHORT QUEUES. The reference's own loop (runCUDA: qt/cudarunthread.cpp:21-41) renders ONE sample per call: a few hundred
+	// thousand rays per launch, fewer than the grid has lanes. A wave that claimed CHUNK of them would walk them four deep while
+	// four waves in five found the queue drained (0.40 ms per launch, eight times the full-queue cost per ray). So a claim is no
+	// larger than the queue's share of one wave, in whole wave-widths; long queues keep CHUNK. Only the schedule depends on it.
+	int chunk = CHUNK;
+	{
+		const int nwaves = (int)gridDim.x * (PT_BLOCK / 64);
+		if (n < nwaves * CHUNK) {
+			const int share = (int)__builtin_amdgcn_readfirstlane((n + nwaves - 1) / nwaves);
+			chunk = (share + 63) & ~63;
+			chunk = chunk < 64 ? 64 : chunk > CHUNK ? CHUNK : chunk;
+		}
+	}
 
 	enum { IDLE = 0, DESCEND = 1, DONE = 2 };
 	int state = IDLE;
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 				if (idle == 0ull) break;
 				if (feed.next >= feed.hi) {
 					if (feed.exhausted) break;
-					feed_claim(feed, cursor, n, CHUNK);
+					feed_claim(feed, cursor, n, chunk);
 					if (feed.exhausted) break;
 				}
 				const int mine = feed.next + (int)__popcll(idle & lt);

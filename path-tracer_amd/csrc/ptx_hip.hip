@@ -62,7 +62,16 @@ struct PtxCtx {
 	int grp_pad_ppm;                        // group-box padding used by the next ptx_scene_upload (env PTX_GRP_PAD_PPM)
 	bool profiling;
 	std::vector<hipEvent_t>* prof_ev[2];    // [0] traverse, [1] segment: start/stop event pairs
+	// look-ahead window of ptx_render_sample_ahead: samples [la_first, la_first + la_count) of (la_scene, la_seed, camera
+	// generation la_gen) are traced and their radiance is parked in wf.rad, one plane per sample; la_window = the size
+	// asked for when the window was rendered (doubles while calls continue it, back to 1 on anything else)
+	int la_first, la_count, la_window;
+	uint64_t la_seed, la_gen, cam_gen;
+	const PtxScene* la_scene;
 };
+
+// whatever overwrites wf.rad, or changes what a sample is (camera, scheduling knobs, scene), ends the window
+static void la_drop(PtxCtx* c) { c->la_count = 0; c->la_window = 0; c->la_scene = NULL; }
 
 struct PtxScene {
 	int device;
@@ -181,6 +190,7 @@ static void tune_defaults(PtxCtx* c) {
 extern "C" int ptx_ctx_tune(PtxCtx* ctx, const char* key, int value) {
 	if (!ctx || !key) return fail(PTX_E_INVALID, "ptx_ctx_tune: NULL argument");
 	const Tuning d = tuning_defaults();
+	la_drop(ctx);   // some knobs can change what a sample is on adversarial rays (trav_variant, wide_margin_ppm)
 	if (!strcmp(key, "trav_variant")) {
 		if (value >= 0 && value != 0 && value != 7 && value != 9 && value != 13 && value != 14 && value != 15)
 			return fail(PTX_E_INVALID, "ptx_ctx_tune: trav_variant %d is not in this build (0, 7, 9, 13, 14, 15)", value);
@@ -230,6 +240,7 @@ extern "C" int ptx_ctx_create(int device, PtxCtx** out) {
 extern "C" int ptx_render_cleanup(PtxCtx* ctx);
 
 static void wf_free(PtxCtx* c) {
+	la_drop(c);
 	void* ptrs[] = {c->wf.s0, c->wf.s1, c->wf.s2, c->wf.s3, c->wf.rad, c->wf.counters, c->wf.retry};
 	for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i)
 		if (ptrs[i]) hipFree(ptrs[i]);
@@ -1084,7 +1095,7 @@ extern "C" int ptx_scene_upload(PtxCtx* ctx, const PtxSceneDesc* d, PtxScene** o
 
 extern "C" int ptx_scene_free(PtxCtx* ctx, PtxScene* scene) {
 	if (!scene) return PTX_OK;
-	if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+	if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); if (ctx->la_scene == scene) la_drop(ctx); }
 	free_scene_allocs(scene);
 	delete scene;
 	return PTX_OK;
@@ -1116,6 +1127,8 @@ extern "C" int ptx_render_init(PtxCtx* ctx, const PtxCamera* cam, void* external
 	if (!ctx || !cam) return fail(PTX_E_INVALID, "ptx_render_init: NULL argument");
 	HIP_TRY(hipSetDevice(ctx->device));
 	if (ctx->has_render) ptx_render_cleanup(ctx);
+	la_drop(ctx);
+	ctx->cam_gen++;
 	int rc = fill_camera(cam, &ctx->cam);
 	if (rc != PTX_OK) return rc;
 	const size_t bytes = (size_t)cam->width * (size_t)cam->height * sizeof(float4);
@@ -1136,6 +1149,8 @@ extern "C" int ptx_render_set_camera(PtxCtx* ctx, const PtxCamera* cam) {
 	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_render_set_camera before ptx_render_init");
 	if (cam->width != ctx->cam.width || cam->height != ctx->cam.height)
 		return fail(PTX_E_INVALID, "resolution change %dx%d -> %dx%d needs ptx_render_init", ctx->cam.width, ctx->cam.height, cam->width, cam->height);
+	la_drop(ctx);   // samples traced ahead belong to the old camera
+	ctx->cam_gen++;
 	return fill_camera(cam, &ctx->cam);
 }
 
@@ -1246,17 +1261,31 @@ static void launch_traversal(PtxCtx* ctx, const PtxScene* scene, const WfParams&
 #undef COOP
 }
 
-extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
-                                  uint64_t seed, int collect_stats) {
+// one-lane-per-pixel megakernel instead of the wavefront pipeline: the AABB debug view, PTX_MEGAKERNEL, bounce limits and mesh
+// counts beyond the wavefront kernels' tables
+static bool uses_megakernel(const PtxCtx* ctx, const PtxScene* scene) {
+	return ctx->cam.aabb_mode || ctx->force_megakernel || ctx->cam.max_bounces > PT_WF_MAX_BOUNCES || scene->num_big > PT_MAX_BIG;
+}
+
+// The render pass behind ptx_render_samples and ptx_render_sample_ahead. `park` != NULL (wavefront pipeline only): ONE pass of at
+// most num_samples samples is traced and NOT accumulated - its radiance stays parked in wf.rad, plane s = sample first_sample + s -
+// and *park = the number of samples it held (fewer than asked for if the path state of that many does not fit); `reserve` = the
+// pass size to allocate for at once if the device has the room (the window's ramp 1, 2, 4 ... would otherwise free and allocate
+// the state buffers at every step: 120 ms over the first loop of the headline frame).
+static int render_samples_impl(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
+                               uint64_t seed, int collect_stats, int* park, int reserve = 0) {
 	int rc = check_scene(ctx, scene, "ptx_render_samples");
 	if (rc != PTX_OK) return rc;
 	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_render_samples before ptx_render_init");
 	if (first_sample < 0 || num_samples < 0 || (int64_t)first_sample + num_samples > 0x7fffffff)
 		return fail(PTX_E_INVALID, "sample range [%d,+%d)", first_sample, num_samples);
+	if (park) *park = 0;
 	if (num_samples == 0) return PTX_OK;
 	HIP_TRY(hipSetDevice(ctx->device));
+	la_drop(ctx);   // this pass overwrites the parked radiance of any window traced ahead
 	const uint32_t k0 = (uint32_t)(seed & 0xffffffffu), k1 = (uint32_t)(seed >> 32);
-	if (ctx->cam.aabb_mode || ctx->force_megakernel || ctx->cam.max_bounces > PT_WF_MAX_BOUNCES || scene->num_big > PT_MAX_BIG) {
+	if (uses_megakernel(ctx, scene)) {
+		if (park) return fail(PTX_E_STATE, "render_samples_impl: no parked pass through the megakernel");
 		// one-lane-per-pixel megakernel: kept for the AABB debug view (its mask is a float product
 		// taken in object order) and as an A/B reference (PTX_MEGAKERNEL=1)
 		const int tiles_x = (ctx->cam.width + 15) / 16, tiles_y = (ctx->cam.height + 15) / 16;
@@ -1289,14 +1318,20 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 	const int nsets = seg_loop ? (maxb > 1 ? maxb : 1) : 2;
 	// 64 B of state per path and set, a queue entry per set, 12 B of parked radiance: if the device cannot hold the preferred
 	// batch (other tenants, huge frames, deep bounce limits), halve it rather than fail; the result does not depend on the batch size
+	while (reserve > 1 && npt * (size_t)reserve > ((size_t)1 << 28)) reserve >>= 1;
 	for (;;) {
-		rc = wf_ensure(ctx, (npt * (size_t)batch + WF_ROUNDS * PT_BLOCK), npix * (size_t)batch, scene->num_big, nsets);
-		if (rc == PTX_OK || batch == 1) break;
+		const int room = reserve > batch ? reserve : batch;
+		rc = wf_ensure(ctx, (npt * (size_t)room + WF_ROUNDS * PT_BLOCK), npix * (size_t)room, scene->num_big, nsets);
+		if (rc == PTX_OK || room == 1) break;
 		wf_free(ctx);
 		(void)hipGetLastError();   // clear the sticky out-of-memory status
-		batch >>= 1;
+		if (reserve > batch) reserve = 0; else batch >>= 1;
 	}
 	if (rc != PTX_OK) return rc;
+	if (park) {   // one pass, whatever it holds
+		if (num_samples > batch) num_samples = batch;
+		*park = num_samples;
+	}
 	const size_t stride = ctx->wf_paths;
 	for (int s0 = first_sample; s0 < first_sample + num_samples; s0 += batch) {
 		const int b = (first_sample + num_samples - s0) < batch ? (first_sample + num_samples - s0) : batch;
@@ -1379,10 +1414,54 @@ extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_
 				HIP_TRY(hipGetLastError());
 			}
 		}
+		if (park) break;   // the caller adds the planes one by one
 		hipLaunchKernelGGL(wf_accumulate_kernel, dim3((unsigned)((npix + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream,
 		                   ctx->accum, (const Rad3*)wp.rad, (int)npix, b);
 		HIP_TRY(hipGetLastError());
 	}
+	return PTX_OK;
+}
+
+extern "C" int ptx_render_samples(PtxCtx* ctx, const PtxScene* scene, int first_sample, int num_samples,
+                                  uint64_t seed, int collect_stats) {
+	return render_samples_impl(ctx, scene, first_sample, num_samples, seed, collect_stats, NULL);
+}
+
+// The reference renders ONE sample per call (kernelMain, src/kernel.cu:59-91, in the loop of qt/cudarunthread.cpp:21-41). A
+// one-sample pass cannot fill this chip: the headline frame has 2 M paths per sample for 0.4 M lanes, and every launch of the
+// pass lasts as long as its longest ray (2.3 ms per sample, against 0.48 ms per sample in a 128-sample pass). So this entry point
+// ADDS exactly one sample to the accumulation buffer, like ptx_render_samples(ctx, scene, sample, 1, seed, 0) and bit for bit
+// (radiance is parked per (sample, pixel) and added in sample order in either case), but TRACES AHEAD: when `sample` is not in
+// the window it holds, it traces [sample, sample + w) in one pass, parks the radiance and adds plane 0; the following calls
+// find their sample in the window and only add its plane (one 14-us kernel). w starts at 1 and doubles while the calls continue
+// the window (sample = its end, same scene / seed / camera), up to max_ahead: a moving camera pays for one sample per frame, a
+// standing one gets passes of max_ahead. Anything that changes what a sample is, or overwrites the parked radiance, ends the
+// window: ptx_render_set_camera / _init / _cleanup, ptx_render_samples, ptx_ctx_tune, ptx_scene_free.
+extern "C" int ptx_render_sample_ahead(PtxCtx* ctx, const PtxScene* scene, int sample, uint64_t seed, int max_ahead) {
+	int rc = check_scene(ctx, scene, "ptx_render_sample_ahead");
+	if (rc != PTX_OK) return rc;
+	if (!ctx->has_render) return fail(PTX_E_STATE, "ptx_render_sample_ahead before ptx_render_init");
+	if (sample < 0 || sample == 0x7fffffff) return fail(PTX_E_INVALID, "ptx_render_sample_ahead: sample %d", sample);
+	if (max_ahead <= 1 || uses_megakernel(ctx, scene)) return render_samples_impl(ctx, scene, sample, 1, seed, 0, NULL);
+	HIP_TRY(hipSetDevice(ctx->device));
+	const bool same = ctx->la_scene == scene && ctx->la_seed == seed && ctx->la_gen == ctx->cam_gen;
+	const bool held = same && ctx->la_count > 0 && sample >= ctx->la_first && sample - ctx->la_first < ctx->la_count;
+	if (!held) {
+		int w = 1;
+		if (same && ctx->la_window > 0 && sample == ctx->la_first + ctx->la_count) w = ctx->la_window * 2;
+		if (w > max_ahead) w = max_ahead;
+		if (w > ctx->wf_batch) w = ctx->wf_batch;
+		if (w > 0x7fffffff - sample) w = 0x7fffffff - sample;
+		int got = 0;
+		rc = render_samples_impl(ctx, scene, sample, w, seed, 0, &got, max_ahead < ctx->wf_batch ? max_ahead : ctx->wf_batch);   // drops the old window first
+		if (rc != PTX_OK) return rc;
+		ctx->la_scene = scene; ctx->la_seed = seed; ctx->la_gen = ctx->cam_gen;
+		ctx->la_first = sample; ctx->la_count = got; ctx->la_window = w;
+	}
+	const size_t npix = (size_t)ctx->cam.width * ctx->cam.height;
+	hipLaunchKernelGGL(wf_accumulate_kernel, dim3((unsigned)((npix + PT_BLOCK - 1) / PT_BLOCK)), dim3(PT_BLOCK), 0, ctx->stream,
+	                   ctx->accum, (const Rad3*)ctx->wf.rad + (size_t)(sample - ctx->la_first) * npix, (int)npix, 1);
+	HIP_TRY(hipGetLastError());
 	return PTX_OK;
 }
 

@@ -24,6 +24,9 @@ extern "C" void pth_set_device(int device) { hip_device_id = device; }
 extern "C" void pth_set_device_upload(int enabled) { setDeviceUploadEnabled(enabled != 0); }
 extern "C" void pth_set_procedural_car_triangles(int n) { setProceduralCarTriangles(n); }
 extern "C" void pth_set_seed(uint64_t seed) { kernelSetSeed(seed); }
+// samples the one-sample-per-call loop (pth_run_iteration = runCUDA) may trace ahead; 1 = none
+extern "C" void pth_set_look_ahead(int samples) { kernelSetLookAhead(samples); }
+extern "C" int pth_look_ahead(void) { return kernelLookAhead(); }
 
 extern "C" int pth_scene_load(const char* json_path, int width, int height, int textures, int preview, int aabb, int bounces) {
 	Json::Value jscene;

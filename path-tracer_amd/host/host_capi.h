@@ -16,6 +16,9 @@ void pth_set_device(int device);
 void pth_set_device_upload(int enabled);            /* 0: host-side load only (CPU tests) */
 void pth_set_procedural_car_triangles(int n);
 void pth_set_seed(uint64_t seed);
+/* samples pth_run_iteration (= runCUDA) may trace ahead of the one it adds (ptx_render_sample_ahead); 1 = none; default 16 */
+void pth_set_look_ahead(int samples);
+int pth_look_ahead(void);
 
 /* parseJsonScene + sceneState.load (reference: qt/sceneloaderthread.cpp:11-23); width/height > 0
  * force the resolution, textures/preview/aabb/bounces < 0 keep the Camera::init defaults except

@@ -3,6 +3,7 @@
 #include "pathtracing.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 int hip_device_id = 0;
@@ -12,6 +13,9 @@ float4* device_accum_image = NULL;
 
 static PtxCtx* g_ctx = NULL;
 static uint64_t g_seed = 0;
+// samples the one-sample-per-call loop may trace ahead (ptx_render_sample_ahead); PTX_LOOK_AHEAD in the environment, or
+// kernelSetLookAhead; 1 = every call traces its own sample only, as the reference does
+static int g_look_ahead = -1;
 static int g_last_status = PTX_OK;
 static bool g_render_ready = false;
 
@@ -31,6 +35,15 @@ void kernelShutdown() {
 }
 
 void kernelSetSeed(uint64_t seed) { g_seed = seed; }
+void kernelSetLookAhead(int samples) { g_look_ahead = samples < 1 ? 1 : samples; }
+int kernelLookAhead() {
+	if (g_look_ahead < 0) {
+		const char* e = getenv("PTX_LOOK_AHEAD");
+		const int v = e && *e ? atoi(e) : KERNEL_LOOK_AHEAD_DEFAULT;
+		g_look_ahead = v < 1 ? 1 : v;
+	}
+	return g_look_ahead;
+}
 uint64_t kernelSeed() { return g_seed; }
 
 void fillPtxCamera(const Camera& cam, PtxCamera* out) {
@@ -80,6 +93,8 @@ void kernelInit(const Scene& scene) { initPathTracing(scene); }
 // reference: src/kernel.cu:30-35
 void kernelCleanUp() { cleanUpPathTracing(); }
 
+static int syncCamera(PtxCtx* ctx, Scene& scene);
+
 unsigned int wang_unhash(unsigned int h) {
 	h ^= (h >> 15) ^ (h >> 30);                 // undo seed ^= seed >> 15
 	h *= 0xfb699ca5u;                           // inverse of 0x27d4eb2d modulo 2^32
@@ -94,20 +109,35 @@ void runPathTracing(Scene& scene, int iterHash, int jitterHash) {
 	(void)jitterHash;
 	const unsigned int iter = wang_unhash((unsigned int)iterHash);
 	if (iter < 1u || iter > 0x7fffffffu) { g_last_status = PTX_E_INVALID; return; }
-	renderSamples(scene, (int)iter - 1, 1, false);
+	renderOneSample(scene, (int)iter - 1);
+}
+
+// What one iteration of the reference's loop adds to the accumulation buffer: sample `sample`, exactly. The library may trace
+// the samples that follow it in the same pass and keep their radiance parked (ptx_render_sample_ahead): the buffer after this
+// call is bit for bit the one-sample-per-call buffer, only the following calls find their work done.
+int renderOneSample(Scene& scene, int sample) {
+	PtxCtx* ctx = kernelContext();
+	if (!ctx || !g_render_ready) return g_last_status = PTX_E_STATE;
+	int rc = syncCamera(ctx, scene);
+	if (rc != PTX_OK) return g_last_status = rc;
+	return g_last_status = ptx_render_sample_ahead(ctx, (const PtxScene*)scene.dv_wobjects_ptr, sample, g_seed, kernelLookAhead());
+}
+
+// reference: src/pathtracing.cu:166-172 - camera changed: regenerate primary rays (here: the kernels' camera block)
+static int syncCamera(PtxCtx* ctx, Scene& scene) {
+	if (!scene.camera.changed) return PTX_OK;
+	PtxCamera pc;
+	fillPtxCamera(scene.camera, &pc);
+	int rc = ptx_render_set_camera(ctx, &pc);
+	if (rc == PTX_OK) scene.camera.changed = false;
+	return rc;
 }
 
 int renderSamples(Scene& scene, int first_sample, int num_samples, bool collect_stats) {
 	PtxCtx* ctx = kernelContext();
 	if (!ctx || !g_render_ready) return g_last_status = PTX_E_STATE;
-	if (scene.camera.changed) {
-		// reference: src/pathtracing.cu:166-172 — camera changed: regenerate primary rays
-		PtxCamera pc;
-		fillPtxCamera(scene.camera, &pc);
-		int rc = ptx_render_set_camera(ctx, &pc);
-		if (rc != PTX_OK) return g_last_status = rc;
-		scene.camera.changed = false;
-	}
+	int rc = syncCamera(ctx, scene);
+	if (rc != PTX_OK) return g_last_status = rc;
 	return g_last_status = ptx_render_samples(ctx, (const PtxScene*)scene.dv_wobjects_ptr, first_sample, num_samples, g_seed,
 	                                          collect_stats ? 1 : 0);
 }

@@ -29,4 +29,11 @@ void kernelShutdown();
 void kernelSetSeed(uint64_t seed);
 uint64_t kernelSeed();
 int renderSamples(Scene& scene, int first_sample, int num_samples, bool collect_stats);
+// One iteration's sample (what runPathTracing renders): adds exactly sample `sample`; the library may trace up to
+// kernelLookAhead() - 1 following samples in the same pass (ptx_render_sample_ahead). Default 16, PTX_LOOK_AHEAD in the
+// environment; 1 = the reference's schedule, one pass per call.
+#define KERNEL_LOOK_AHEAD_DEFAULT 16
+int renderOneSample(Scene& scene, int sample);
+void kernelSetLookAhead(int samples);
+int kernelLookAhead();
 void fillPtxCamera(const Camera& cam, PtxCamera* out);

@@ -135,7 +135,7 @@ int main(int argc, char** argv) {
 		for (int i = start + 1; i <= spp; ++i) {
 			if (i == 1) runCUDA(pbo_dptr, scene, i);   // iteration 1 clears the buffer, as in the reference
 			else {
-				if (renderSamples(scene, i - 1, 1, false) != PTX_OK) { fprintf(stderr, "%s\n", ptx_last_error()); return 1; }
+				if (renderOneSample(scene, i - 1) != PTX_OK) { fprintf(stderr, "%s\n", ptx_last_error()); return 1; }
 				ptx_tonemap(ctx, i, scene.camera.projection.gamma_corr, (unsigned char*)pbo.data());
 			}
 			if (checkCudaError("runCUDA")) return 1;
