@@ -50,6 +50,9 @@
 #include "pt_wavefront.h"
 
 #define WFW_UNIT_CAP 320
+#ifndef WFW_CLAIMS_MIN
+#define WFW_CLAIMS_MIN 8   /* a short queue is cut so that every wave of the grid gets this many claims (1 / 4 / 8: 16-sample pass 10.00 / 9.87 / 9.83 ms, one-sample pass 2.31 / 2.23 / 2.23; a full pass does not notice) */
+#endif
 #define WFW_WAVE_BYTES (64 * 8 + 64 * 4 + WFW_UNIT_CAP * 4)   /* keys, flags, units */
 #define WFW_BYTES ((PT_BLOCK / 64) * WFW_WAVE_BYTES)
 #define WFW_STACK_ENTRY_BYTES 6                                         /* link (4) + entry distance as bf16 (2) */
@@ -89,12 +92,13 @@ __global__ __launch_bounds__(PT_BLOCK, OCC) void wf_traverse_wide_kernel(DevScen
 	// SHORT QUEUES. The reference's own loop (runCUDA: qt/cudarunthread.cpp:21-41) renders ONE sample per call: a few hundred
 	// thousand rays per launch, fewer than the grid has lanes. A wave that claimed CHUNK of them would walk them four deep while
 	// four waves in five found the queue drained (0.40 ms per launch, eight times the full-queue cost per ray). So a claim is no
-	// larger than the queue's share of one wave, in whole wave-widths; long queues keep CHUNK. Only the schedule depends on it.
+	// larger than 1 / WFW_CLAIMS_MIN of the queue's share of one wave, in whole wave-widths (the shorter passes of the look-ahead
+	// windows, ptx_render_sample_ahead, balance better for it too); long queues keep CHUNK. Only the schedule depends on it.
 	int chunk = CHUNK;
 	{
 		const int nwaves = (int)gridDim.x * (PT_BLOCK / 64);
-		if (n < nwaves * CHUNK) {
-			const int share = (int)__builtin_amdgcn_readfirstlane((n + nwaves - 1) / nwaves);
+		if (n < nwaves * CHUNK * WFW_CLAIMS_MIN) {
+			const int share = (int)__builtin_amdgcn_readfirstlane((n + nwaves * WFW_CLAIMS_MIN - 1) / (nwaves * WFW_CLAIMS_MIN));
 			chunk = (share + 63) & ~63;
 			chunk = chunk < 64 ? 64 : chunk > CHUNK ? CHUNK : chunk;
 		}
