@@ -100,7 +100,7 @@ PTX_SYMBOLS = [
     "ptx_last_error", "ptx_version", "ptx_device_count", "ptx_device_info", "ptx_ctx_create", "ptx_ctx_destroy",
     "ptx_scene_upload", "ptx_scene_free", "ptx_scene_device_bytes", "ptx_scene_wide_sah_objects", "ptx_render_init", "ptx_render_set_camera",
     "ptx_render_cleanup", "ptx_accum_clear", "ptx_render_samples", "ptx_render_sync", "ptx_accum_device_ptr",
-    "ptx_render_sample_ahead", "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_stats_get", "ptx_stats_reset",
+    "ptx_render_sample_ahead", "ptx_accum_download", "ptx_accum_upload", "ptx_tonemap", "ptx_host_alloc", "ptx_host_free", "ptx_stats_get", "ptx_stats_reset",
     "ptx_wavefront_counts", "ptx_ctx_tune", "ptx_profile_enable", "ptx_profile_get", "ptx_timer_begin", "ptx_timer_end", "ptx_trace_rays", "ptx_trace_rays_queued", "ptx_generate_rays", "ptx_bsdf_eval", "ptx_radiance_sample", "ptx_selftest_rcp", "ptx_selftest_vec3",
 ]
 
@@ -144,6 +144,8 @@ def lib():
         L.ptx_accum_upload.argtypes = [vp, fp]
         L.ptx_tonemap.argtypes = [vp, i32, f32, C.POINTER(C.c_ubyte)]
         L.ptx_stats_get.argtypes = [vp, C.POINTER(PtxStats)]
+        L.ptx_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.ptx_host_free.argtypes = [vp, vp]
         L.ptx_stats_reset.argtypes = [vp]
         L.ptx_wavefront_counts.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.ptx_ctx_tune.argtypes = [vp, C.c_char_p, i32]

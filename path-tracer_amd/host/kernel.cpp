@@ -35,6 +35,14 @@ void kernelShutdown() {
 }
 
 void kernelSetSeed(uint64_t seed) { g_seed = seed; }
+
+uchar4* kernelAllocPBO(size_t pixels) {
+	PtxCtx* ctx = kernelContext();
+	void* p = NULL;
+	if (!ctx || ptx_host_alloc(ctx, pixels * sizeof(uchar4), &p) != PTX_OK) return NULL;
+	return (uchar4*)p;
+}
+void kernelFreePBO(uchar4* pbo) { if (g_ctx && pbo) ptx_host_free(g_ctx, pbo); }
 void kernelSetLookAhead(int samples) { g_look_ahead = samples < 1 ? 1 : samples; }
 int kernelLookAhead() {
 	if (g_look_ahead < 0) {

@@ -35,5 +35,9 @@ int renderSamples(Scene& scene, int first_sample, int num_samples, bool collect_
 #define KERNEL_LOOK_AHEAD_DEFAULT 16
 int renderOneSample(Scene& scene, int sample);
 void kernelSetLookAhead(int samples);
+// The display buffer (reference: the GL pixel buffer behind pbo_dptr, mapped once: qt/previewglwidget.cpp:80-86): page-locked
+// host memory of `pixels` uchar4, so that every iteration's tone-mapped image arrives at DMA speed; NULL without a device.
+uchar4* kernelAllocPBO(size_t pixels);
+void kernelFreePBO(uchar4* pbo);
 int kernelLookAhead();
 void fillPtxCamera(const Camera& cam, PtxCamera* out);

@@ -78,10 +78,16 @@ int main(int argc, char** argv) {
 	sceneState.cameraChanged(false, NULL);
 	scene.camera.changed = false;
 	const int W = scene.camera.projection.width, H = scene.camera.projection.height;
-	std::vector<uchar4> pbo((size_t)W * H);
-	pbo_dptr = pbo.data();
 	kernelInit(scene);
 	if (checkCudaError("kernelInit")) return 1;
+	// the display buffer: page-locked (kernelAllocPBO), as the reference's mapped pixel buffer is device-visible
+	struct Pbo {
+		uchar4* p; size_t n;
+		uchar4* data() { return p; }
+		const uchar4& operator[](size_t i) const { return p[i]; }
+	} pbo = {kernelAllocPBO((size_t)W * H), (size_t)W * H};
+	if (!pbo.p) { fprintf(stderr, "display buffer: %s\n", ptx_last_error()); return 1; }
+	pbo_dptr = pbo.data();
 
 	PtxCtx* ctx = kernelContext();
 	// on-screen orientation of the reference: buffer mirrored horizontally (qt/previewglwidget.cpp:111-116)
@@ -176,6 +182,7 @@ int main(int argc, char** argv) {
 		if (!writePFM(out_pfm, W, H, rgbf.data(), err)) fprintf(stderr, "%s\n", err.c_str());
 	}
 	kernelCleanUp();
+	kernelFreePBO(pbo.p);
 	sceneState.clean();
 	kernelShutdown();
 	return 0;

@@ -133,3 +133,27 @@ def test_sample_ahead_in_megakernel_and_debug_modes_renders_its_own_sample(pt, o
         pt.check(L.ptx_render_sample_ahead(ctx, scene, s, 0, 16))
     ref, _ = orc.render(desc, cam, 0, 5, 0)
     assert np.array_equal(_accum(pt, ctx, cam).view(np.uint32), ref.view(np.uint32))
+
+
+def test_page_locked_display_buffer_receives_the_same_image(pt, ctx):
+    """ptx_host_alloc (what kernelAllocPBO hands the render loop in place of the reference's mapped pixel buffer): the
+    tone-mapped image written into it equals the one written into ordinary memory; freeing NULL is allowed."""
+    H, L = pt.host(), pt.lib()
+    desc, cam = pt.load_scene("geoms", width=64, height=48)
+    scene = H.pth_scene_device()
+    gpuops.render_init(ctx, cam)
+    gpuops.render(ctx, scene, cam, 0, 6, 0)
+    n = cam.width * cam.height
+    plain = np.zeros((n, 4), np.uint8)
+    pt.check(L.ptx_tonemap(ctx, 6, C.c_float(cam.gamma_corr), plain.ctypes.data_as(C.POINTER(C.c_ubyte))))
+    raw = C.c_void_p()
+    pt.check(L.ptx_host_alloc(ctx, n * 4, C.byref(raw)))
+    assert raw.value
+    try:
+        pt.check(L.ptx_tonemap(ctx, 6, C.c_float(cam.gamma_corr), C.cast(raw, C.POINTER(C.c_ubyte))))
+        locked = np.ctypeslib.as_array(C.cast(raw, C.POINTER(C.c_ubyte)), shape=(n, 4)).copy()
+    finally:
+        pt.check(L.ptx_host_free(ctx, raw))
+    assert plain.any() and np.array_equal(plain, locked)
+    pt.check(L.ptx_host_free(ctx, None))
+    assert L.ptx_host_alloc(ctx, 0, C.byref(raw)) != 0

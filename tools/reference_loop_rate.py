@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--modes", default="loop,render1,tonemap,batch")
-    ap.add_argument("--pinned", type=int, default=0, help="1: the host image is page-locked memory (torch pin_memory)")
+    ap.add_argument("--pinned", type=int, default=0, help="1: the host image is page-locked memory (ptx_host_alloc)")
     args = ap.parse_args()
     import numpy as np
     pt = importlib.import_module("path-tracer_amd")
@@ -43,11 +43,9 @@ def main():
     ctx = H.pth_context()
     pt.check(H.pth_kernel_init(), "kernelInit")
     n_pix = cam.width * cam.height
-    if args.pinned:   # page-locked host image straight from the HIP runtime (hipHostMalloc)
-        hip = C.CDLL("libamdhip64.so")
+    if args.pinned:   # page-locked host image from the library (ptx_host_alloc = what kernelAllocPBO hands the render loop)
         raw = C.c_void_p()
-        if hip.hipHostMalloc(C.byref(raw), C.c_size_t(n_pix * 4), C.c_uint(0)) != 0:
-            raise SystemExit("hipHostMalloc failed")
+        pt.check(L.ptx_host_alloc(ctx, n_pix * 4, C.byref(raw)), "ptx_host_alloc")
         pbo_ptr = C.cast(raw, C.POINTER(C.c_ubyte))
     else:
         pbo = np.zeros((n_pix, 4), np.uint8)
