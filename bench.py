@@ -123,6 +123,7 @@ def main():
                     help="strong scaling: a step is ONE image of this many samples per pixel split over the ranks (all-reduce and "
                          "download to rank 0 inside the step)")
     ap.add_argument("--no-strong-leg", action="store_true", help="weak mode: skip the measured 1000-spp strong leg")
+    ap.add_argument("--no-loop-leg", action="store_true", help="skip the timing of the reference's own loop (runCUDA once per sample)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -468,6 +469,31 @@ def main():
                "sample": f"{args.cpu_spp} spp of the full {cam.width}x{cam.height} frame ({rays_n} rays, {dt_n:.1f} s) "
                          f"on {threads} threads (a one-GPU job's share of the {visible} cores visible)"}
 
+    # ---- the reference's OWN loop (N = 1, after everything else): runCUDA(pbo, scene, i) once per sample, one tone-mapped image on
+    # the host per call (qt/cudarunthread.cpp:21-41), through the host layer's default look-ahead and a page-locked display buffer
+    ref_loop = None
+    if world == 1 and not strong and not args.no_loop_leg:
+        raw = C.c_void_p()
+        pt.check(L.ptx_host_alloc(ctx, n_pix * 4, C.byref(raw)), "ptx_host_alloc")
+        pbo = C.cast(raw, C.POINTER(C.c_ubyte))
+        pt.check(H.pth_kernel_init(), "kernelInit")   # the render side again, with the library's own accumulation buffer
+        calls = 128
+        for i in range(1, 4):
+            assert H.pth_run_iteration(i, pbo) == i, H.pth_last_error()
+        pt.check(L.ptx_render_sync(ctx))
+        pt.check(L.ptx_stats_reset(ctx))
+        tl = time.perf_counter()
+        for i in range(4, 4 + calls):
+            assert H.pth_run_iteration(i, pbo) == i, H.pth_last_error()
+        pt.check(L.ptx_render_sync(ctx))
+        dl = time.perf_counter() - tl
+        pt.check(L.ptx_stats_get(ctx, C.byref(stats)))
+        ref_loop = {"ms_per_call": round(1e3 * dl / calls, 3), "calls": calls, "look_ahead_samples": int(H.pth_look_ahead()),
+                    "mrays_per_s_traced": round(stats.rays / dl / 1e6, 1), "samples_per_s": round(n_pix * calls / dl, 1),
+                    "what": "runCUDA(pbo, scene, i) once per sample, a tone-mapped image on the host after every call (page-locked "
+                            "buffer from ptx_host_alloc); rays traced ahead for calls beyond the last one are counted"}
+        pt.check(L.ptx_host_free(ctx, raw))
+
     out = {
         "metric": "Mrays/s (whole node), Lamborghini 1920x1080", "value": round(total_rays / max_elapsed / 1e6, 2),
         "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -487,6 +513,7 @@ def main():
                        "time_to_1k_spp_s": round(strong_1k, 4) if strong_1k is not None else round(1000.0 / (spp * args.steps * world / max_elapsed), 2),
                        "time_to_1k_spp_is": ("MEASURED: one image of 1000 spp split over the ranks by sample index, one all-reduce, on rank 0's host"
                                              if strong_1k is not None else "extrapolated from the weak-scaling steps")}),
+                   **({"reference_loop": ref_loop} if ref_loop is not None else {}),
                    "parallelism": f"spp-split x{world}"},
         "roofline": roofline, "cpu_baseline": cpu,
     }

@@ -1,6 +1,6 @@
 # A/B of environment settings on the bench workload: bash tools/ab_env.sh "VAR=a" "VAR=b" ...
 for e in "$@"; do
-  echo -n "$e: "; env $e timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strong-leg 2>/dev/null | tail -1 | python3 -c "
+  echo -n "$e: "; env $e timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strong-leg --no-loop-leg 2>/dev/null | tail -1 | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; o=r['other_kernel'] or {}
 ks={r['kernel'][:12]:r, (o.get('kernel') or 'none')[:12]:o}

@@ -2,7 +2,7 @@
 # usage: bash tools/ab_run.sh name1 name2 ...
 for n in "$@"; do
   cp ab/$n/libptx_hip.so path-tracer_amd/libptx_hip.so || exit 1
-  echo -n "$n: "; timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strong-leg 2>/dev/null | tail -1 | python3 -c "
+  echo -n "$n: "; timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-strong-leg --no-loop-leg 2>/dev/null | tail -1 | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; o=r['other_kernel'] or {}
 ks={r['kernel'][:12]:r, (o.get('kernel') or 'none')[:12]:o}

@@ -5,8 +5,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 T=${1:-r03}
 O=gpurun_out/prof_$T
 rm -rf $O; mkdir -p $O
-B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-strong-leg"
-timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg > $O/trace.log 2>&1 || exit 1
+B="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-strong-leg --no-loop-leg"
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg --no-loop-leg > $O/trace.log 2>&1 || exit 1
 echo trace done
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1 || exit 2
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1 || exit 3

@@ -55,8 +55,8 @@ for f in sorted(glob.glob(os.path.join(src, "*", "**", "*_counter_collection.csv
         sums[k]["_vgpr"] = float(r["VGPR_Count"]); sums[k]["_sgpr"] = float(r["SGPR_Count"]); sums[k]["_lds"] = float(r["LDS_Block_Size"])
 
 out = {"round": tag, "commit": commit, "csrc_sha1": csrc_sha1(), "compute_units": CUS,
-       "command": "tools/profile_round.sh: rocprofv3 --pmc <one block per pass> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-strong-leg; "
-                  "kernel_stats from rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg",
+       "command": "tools/profile_round.sh: rocprofv3 --pmc <one block per pass> -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-strong-leg --no-loop-leg; "
+                  "kernel_stats from rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-strong-leg --no-loop-leg",
        "note": "counter sums over the dispatches of one bench step (128 spp, 1920x1080 Lamborghini stand-in, real lp560 textures); keys are the "
                "FULL kernel names incl. template arguments; <1,...> kernels are the counting variants of bench.py's roofline leg. "
                "derived: see tools/summarize_round.py",
