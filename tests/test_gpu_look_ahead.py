@@ -157,3 +157,58 @@ def test_page_locked_display_buffer_receives_the_same_image(pt, ctx):
     assert plain.any() and np.array_equal(plain, locked)
     pt.check(L.ptx_host_free(ctx, None))
     assert L.ptx_host_alloc(ctx, 0, C.byref(raw)) != 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_call_sequences_equal_one_pass_per_call(pt, ctx, seed):
+    """Seeded random sequences of what a caller can do between two iterations - the next sample, a jump, a repeat, a batch
+    render, a knob, a camera change back and forth, a cleared buffer, another seed - through ptx_render_sample_ahead with
+    windows up to 8, against the same sequence with one pass per sample."""
+    H, L = pt.host(), pt.lib()
+    desc, cam_a = pt.load_scene("teapot", width=72, height=40)
+    scene = H.pth_scene_device()
+    cam_b = pt.PtxCamera()
+    C.memmove(C.byref(cam_b), C.byref(cam_a), C.sizeof(cam_a))
+    cam_b.position[0] = cam_a.position[0] + 0.5
+    rng = np.random.default_rng(seed)
+    ops, s = [], 0
+    for _ in range(70):
+        r = rng.random()
+        if r < 0.62:
+            ops.append(("one", s, 0)); s += 1
+        elif r < 0.70:
+            s = int(rng.integers(0, 200)); ops.append(("one", s, 0)); s += 1
+        elif r < 0.76:
+            ops.append(("one", max(0, s - 1), 0))
+        elif r < 0.82:
+            n = int(rng.integers(1, 6)); ops.append(("many", s, n)); s += n
+        elif r < 0.87:
+            ops.append(("tune", 0, 0))
+        elif r < 0.93:
+            ops.append(("camera", int(rng.integers(0, 2)), 0))
+        elif r < 0.96:
+            ops.append(("clear", 0, 0))
+        else:
+            ops.append(("one", s, 5)); s += 1
+
+    def run(ahead):
+        gpuops.render_init(ctx, cam_a)
+        pt.check(L.ptx_accum_clear(ctx))
+        for kind, a, b in ops:
+            if kind == "one" and ahead > 0:
+                pt.check(L.ptx_render_sample_ahead(ctx, scene, a, b, ahead))
+            elif kind == "one":
+                pt.check(L.ptx_render_samples(ctx, scene, a, 1, b, 0))
+            elif kind == "many":
+                pt.check(L.ptx_render_samples(ctx, scene, a, b, 0, 0))
+            elif kind == "tune":
+                pt.check(L.ptx_ctx_tune(ctx, b"wf_batch", -1))
+            elif kind == "camera":
+                pt.check(L.ptx_render_set_camera(ctx, C.byref(cam_b if a else cam_a)))
+            elif kind == "clear":
+                pt.check(L.ptx_accum_clear(ctx))
+        return _accum(pt, ctx, cam_a)
+
+    plain = run(0)
+    assert plain.any()
+    assert np.array_equal(plain.view(np.uint32), run(8).view(np.uint32))
