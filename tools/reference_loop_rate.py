@@ -11,6 +11,7 @@ Prints, per mode: ms per iteration, samples/s, Mrays/s (device counters). Modes:
   tonemap     ptx_tonemap alone (kernel + 4 bytes per pixel to the host)
   batch       ptx_render_samples(128 spp) per call (the fast path)
   sweep       pass time against samples per pass
+  verify      the loop's float buffer after --iters calls against one pass of as many samples (bit for bit, at full size)
   ahead=N     sets the look-ahead of the following loops (pth_set_look_ahead; 1 = one pass per call)
 """
 import argparse
@@ -114,6 +115,24 @@ def main():
             sweep()
         elif m == "batch":
             timed("batch", batch, max(2, args.iters // 50), 128)
+        elif m == "verify":   # the loop's buffer after args.iters calls against ONE ptx_render_samples call of as many samples, full size
+            assert H.pth_kernel_init() == 0
+            pt.check(L.ptx_stats_reset(ctx))
+            for i in range(1, args.iters + 1):
+                loop(i)
+            a = np.empty((n_pix, 4), np.float32)
+            pt.check(L.ptx_render_sync(ctx)); pt.check(L.ptx_accum_download(ctx, a.ctypes.data_as(C.POINTER(C.c_float))))
+            r_loop = rays()
+            assert H.pth_kernel_init() == 0
+            pt.check(L.ptx_stats_reset(ctx))
+            pt.check(H.pth_render_samples(0, args.iters, 0))
+            b = np.empty((n_pix, 4), np.float32)
+            pt.check(L.ptx_render_sync(ctx)); pt.check(L.ptx_accum_download(ctx, b.ctypes.data_as(C.POINTER(C.c_float))))
+            diff = int((a.view(np.uint32) != b.view(np.uint32)).any(axis=1).sum())
+            print(f"verify: {args.iters} runCUDA calls (look-ahead {H.pth_look_ahead()}) against one pass of {args.iters} samples: "
+                  f"{diff} of {n_pix} pixels differ; segments traced {r_loop} (loop, incl. ahead of the last call) / {rays()} (pass)")
+            if diff:
+                raise SystemExit(1)
         elif m.startswith("ahead="):
             H.pth_set_look_ahead(int(m[6:]))
             print(f"look-ahead {H.pth_look_ahead()}")
