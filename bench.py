@@ -32,6 +32,8 @@ Prints one JSON line (rank 0) with the contract fields plus
                   twin; `logical` = the reference algorithm's figures of SURVEY.md 8(d), a side field;
                   `algorithmic` (in each kernel's view) = the HBM bytes the kernel cannot avoid (path state in /
                   out, queue entries, shading records, texels, parked radiance) over its launch time against 8 TB/s.
+  config.reference_loop   (N = 1) the reference's OWN loop timed after everything else: runCUDA(pbo, scene, i) once per sample with a
+                  tone-mapped image on the host after every call (ptx_render_sample_ahead behind it: DESIGN.md 3.6); not part of `value`.
   "cpu_baseline"  the CPU oracle (a straight multithreaded port, oracle/) timed on this box's host
                   cores on a bounded sample of the same workload (+ a 1-thread figure).
 """
