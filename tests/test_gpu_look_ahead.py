@@ -212,3 +212,33 @@ def test_random_call_sequences_equal_one_pass_per_call(pt, ctx, seed):
     plain = run(0)
     assert plain.any()
     assert np.array_equal(plain.view(np.uint32), run(8).view(np.uint32))
+
+
+def test_textured_headline_scene_through_the_loop(pt, orc, ctx, look_ahead):
+    """The headline scene's own ingredients - textured sky cube and floor, the car's 22 textures and 83 materials (a 20 000-triangle
+    car here), mirrors and glass, the retry queue - through 24 calls of runCUDA with windows up to 8, into a page-locked display
+    buffer: the float buffer equals one pass of 24 samples and the oracle, the displayed image equals the oracle's tone map."""
+    H, L = pt.host(), pt.lib()
+    look_ahead(8)
+    desc, cam = pt.load_scene("lamborghini", width=160, height=90, textures=1, car_tris=20000)
+    scene = H.pth_scene_device()
+    n = cam.width * cam.height
+    assert H.pth_kernel_init() == 0
+    raw = C.c_void_p()
+    pt.check(L.ptx_host_alloc(ctx, n * 4, C.byref(raw)))
+    try:
+        pp = C.cast(raw, C.POINTER(C.c_ubyte))
+        for it in range(1, 25):
+            assert H.pth_run_iteration(it, pp) == it
+        shown = np.ctypeslib.as_array(pp, shape=(n, 4)).copy()
+    finally:
+        pt.check(L.ptx_host_free(ctx, raw))
+    loop = _accum(pt, ctx, cam)
+    batch, st = gpuops.render(ctx, scene, cam, 0, 24, 0)
+    assert np.array_equal(loop.view(np.uint32), batch.view(np.uint32))
+    ref, st_o = orc.render(desc, cam, 0, 24, 0)
+    assert np.array_equal(loop.view(np.uint32), ref.view(np.uint32))
+    assert st_o.hit_textured > 1000 and st_o.hit_mesh > 1000
+    out_o = np.empty((n, 4), np.uint8)
+    assert orc.lib().orc_tonemap(orc.fptr(ref), n, 24, cam.gamma_corr, out_o.ctypes.data_as(C.POINTER(C.c_ubyte))) == 0
+    assert np.abs(shown.astype(int) - out_o.astype(int)).max() <= 1
