@@ -181,3 +181,20 @@ def test_obj_reader_features(pt, tmp_path):
     assert abc[3].tolist() == [0, 0, 1, 1, 0, 1, 0, 1, 1]
     assert tuple(tri[1].tb) == (1.0, 0.0) and tuple(tri[2].tc) == (0.0, 0.0)
     assert tuple(tri[0].na) == (0.0, 0.0, 1.0)
+
+
+def test_look_ahead_setting_of_the_one_sample_loop(pt):
+    """host/kernel.h: runCUDA may trace kernelLookAhead() - 1 samples ahead of the one it adds; 16 unless PTX_LOOK_AHEAD or
+    kernelSetLookAhead say otherwise, never below 1 (= one pass per call, the reference's schedule). No device needed."""
+    H = pt.host()
+    before = H.pth_look_ahead()
+    try:
+        assert before == int(os.environ.get("PTX_LOOK_AHEAD", "16")) or before >= 1
+        H.pth_set_look_ahead(5)
+        assert H.pth_look_ahead() == 5
+        H.pth_set_look_ahead(0)
+        assert H.pth_look_ahead() == 1
+        H.pth_set_look_ahead(-7)
+        assert H.pth_look_ahead() == 1
+    finally:
+        H.pth_set_look_ahead(before)
